@@ -1,0 +1,51 @@
+"""Seeded synthetic inputs shaped like the reference's datasets.
+
+The reference ships no data (``data/*/README.md`` only give download links), so every
+test / bench uses these generators.  Values are aggregate power in kW, i.e. after the
+reference's ``/1000`` scaling (``configs/config_expes.yaml:15``,
+``src/helpers/torch_dataset.py:63-65``).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# (low kW, high kW, min minutes, max minutes)
+_UKDALE_PULSES = [(2.0, 3.0, 2, 5), (0.8, 2.5, 30, 90)]       # kettle-like, dishwasher-like
+_REFIT_PULSES = [(2.0, 3.0, 2, 6), (0.5, 2.5, 20, 120), (0.1, 0.3, 10, 40)]
+_IDEAL_PULSES = [(7.0, 9.0, 3, 12), (1.5, 3.0, 2, 6)]          # shower-like, kettle-like
+
+
+def _windows(n, length, seed, pulses, clip_hi, p_pulse, dtype):
+    rng = np.random.default_rng(seed)
+    x = np.abs(rng.normal(0.15, 0.05, size=(n, length)))
+    labels = np.zeros(n, dtype=np.int64)
+    for i in range(n):
+        n_p = rng.poisson(p_pulse)
+        for _ in range(n_p):
+            lo, hi, dmin, dmax = pulses[rng.integers(len(pulses))]
+            amp = rng.uniform(lo, hi)
+            dur = int(rng.integers(dmin, dmax + 1))
+            start = int(rng.integers(0, max(1, length - 1)))
+            x[i, start:start + dur] += amp
+            labels[i] = 1
+    x[x < 0.005] = 0.0  # values < 5 W zeroed (data_processing.py:485,510)
+    np.clip(x, 0.0, clip_hi, out=x)
+    return x.astype(dtype), labels
+
+
+def ukdale_windows(n=64, length=1024, seed=0, dtype=np.float32, return_labels=False):
+    """BASELINE config 1/2: base load |N(0.15,0.05)| kW + rectangular pulses, clip [0, 6]."""
+    x, y = _windows(n, length, seed, _UKDALE_PULSES, 6.0, 1.2, dtype)
+    return (x, y) if return_labels else x
+
+
+def refit_windows(n=64, length=1440, seed=0, dtype=np.float32, return_labels=False):
+    """BASELINE config 3: REFIT meter-day windows @1 min, clip [0, 10] kW."""
+    x, y = _windows(n, length, seed, _REFIT_PULSES, 10.0, 2.0, dtype)
+    return (x, y) if return_labels else x
+
+
+def ideal_windows(n=128, length=510, seed=0, dtype=np.float32, return_labels=True):
+    """BASELINE config 4: IDEAL-shaped training windows (no cutoff), ~50/50 labels."""
+    x, y = _windows(n, length, seed, _IDEAL_PULSES, 1e9, 0.7, dtype)
+    return (x, y) if return_labels else x

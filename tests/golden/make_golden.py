@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory FROM THE REFERENCE ITSELF.
+
+Run only in the dev container (``/root/reference`` does not exist on the GPU box):
+
+    python tests/golden/make_golden.py
+
+It imports the reference's own modules (``CamALResNet``, ``CAM``, ``CamAL``,
+``BasedClassifTrainer``) from ``/root/reference``, loads weights produced by this
+repo's seeded generator (``camal_amd.weights.make_state_dict``) into them, runs them on
+this repo's seeded synthetic windows and stores ONLY inputs' seeds/calibration constants
+and the reference's outputs.  No reference source travels.
+
+``src.models.camal.core`` imports ``imblearn`` (absent here) through
+``data_processing``; ``predict/eval/test`` never use it, so an empty placeholder module
+is registered for the import line only.  ``CamAL.train`` is therefore not used here;
+training fixtures drive ``BasedClassifTrainer`` directly.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+
+from camal_amd import synth, weights  # noqa: E402
+
+if "imblearn" not in sys.modules:
+    try:
+        import imblearn  # noqa: F401
+    except Exception:
+        m = types.ModuleType("imblearn")
+        mu = types.ModuleType("imblearn.under_sampling")
+        mu.RandomUnderSampler = object
+        m.under_sampling = mu
+        sys.modules["imblearn"] = m
+        sys.modules["imblearn.under_sampling"] = mu
+
+from src.helpers.class_activation_map import CAM  # noqa: E402
+from src.models.camal.classifiers.camal_resnet import CamALResNet  # noqa: E402
+from src.models.camal.core import CamAL  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+KERNELS = [5, 7, 9, 15, 25]
+
+
+def to_torch_sd(sd):
+    return {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
+
+
+def ref_model(sd):
+    m = CamALResNet(kernel_size=weights.kernel_size_of(sd))
+    m.load_state_dict(to_torch_sd(sd))
+    m.eval()
+    return m
+
+
+def calibrate_heads(data, seed, spread):
+    """Pick linear.weight's gain and linear.bias per member so that the logit difference
+    l1-l0 over `data` has median 0 and standard deviation `spread` (probabilities then
+    spread around 0.5 without saturating).  Uses the reference model."""
+    gains, biases = [], []
+    for k in KERNELS:
+        sd = weights.make_state_dict(k, seed=seed, head_gain=1.0)
+        with torch.no_grad():
+            lg = ref_model(sd)(torch.from_numpy(data[:, None, :]).float()).numpy()
+        d = (lg[:, 1] - lg[:, 0]).astype(np.float64)
+        g = float(np.float32(spread / max(d.std(), 1e-6)))
+        gains.append(g)
+        biases.append((0.0, float(np.float32(-g * np.median(d)))))
+    return gains, biases
+
+
+def run_case(name, data, seed, gain, w_ma=5, gated=False, members=None):
+    members = members or KERNELS
+    data32 = data.astype(np.float32)
+    gains, biases = calibrate_heads(data32, seed, gain)
+    gains = [gains[KERNELS.index(k)] for k in members]
+    biases = [biases[KERNELS.index(k)] for k in members]
+    sds = [weights.make_state_dict(k, seed=seed, head_gain=g, head_bias=b)
+           for k, g, b in zip(members, gains, biases)]
+
+    # --- per member: reference CAM.run window by window (class_activation_map.py:34) ---
+    n, length = data.shape
+    cams = np.zeros((len(members), n, length), np.float32)
+    labels = np.zeros((len(members), n), np.int32)
+    probs = np.zeros((len(members), n, 2), np.float32)
+    logits = np.zeros((len(members), n, 2), np.float32)
+    for e, sd in enumerate(sds):
+        m = ref_model(sd)
+        cam = CAM(model=m, device="cpu", last_conv_layer=m._modules["layers"][2],
+                  fc_layer_name=m._modules["linear"])
+        for i in range(n):
+            c, lab, p = cam.run(instance=data[i], returned_cam_for_label=1)
+            cams[e, i], labels[e, i], probs[e, i] = c, lab, p
+        with torch.no_grad():
+            logits[e] = m(torch.from_numpy(data32[:, None, :])).numpy()
+
+    # --- ensemble: reference CamAL.predict on hand-built camal_logs (core.py:252) ---
+    logs = {"ensemble_training_logs": {}, "camal_predictors_id": [], "is_fitted": True}
+    for e, (k, sd) in enumerate(zip(members, sds)):
+        nm = f"Predictor_{e}"
+        logs["ensemble_training_logs"][nm] = {"kernel_size": k, "best_model_state_dict": to_torch_sd(sd)}
+        logs["camal_predictors_id"].append(nm)
+    camal = CamAL(n_predictors=len(members), device="cpu")
+    camal.camal_logs = logs
+    camal.is_fitted = True
+    captured = {}
+    orig_att = camal.attention_sigmoid_module
+
+    def capture(d, soft_label, w_ma=5):  # records the reference's own intermediate
+        captured["avg_cam"] = np.array(soft_label)
+        return orig_att(d, soft_label, w_ma=w_ma)
+
+    camal.attention_sigmoid_module = capture
+    y = None
+    if gated:
+        # the reference's device != 'cpu' branch (core.py:292-293) computes y from member 0
+        y = camal._predict_subsequence_class(ref_model(sds[0]), data)
+    states, prob_detect = camal.predict(data, y=y, return_prob=True, w_ma=w_ma)
+
+    out = dict(
+        members=np.array(members), seed=np.array(seed), head_gain=np.array(gains, np.float64),
+        head_bias=np.array(biases, np.float64), w_ma=np.array(w_ma), gated=np.array(gated),
+        data=data, cams=cams, labels=labels, probs=probs, logits=logits,
+        avg_cam=captured["avg_cam"], states=states, prob_detect=prob_detect,
+    )
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    on = float((states != 0).mean())
+    print(f"{name}: N={n} L={length} members={members} labels1={labels.mean():.2f} "
+          f"prob_detect in [{prob_detect.min():.3f},{prob_detect.max():.3f}] states_on={on:.3f} "
+          f"size={os.path.getsize(os.path.join(HERE, name + '.npz')) / 1024:.0f} KB")
+
+
+def main():
+    # 1. the BASELINE config-1 shape, shrunk: full ensemble, float32 data
+    run_case("ensemble_l256", synth.ukdale_windows(12, 256, seed=11), seed=101, gain=2.0)
+    # 2. float64 data (output dtype follows the input, quirk 9), ragged length (not a tile multiple)
+    run_case("ensemble_l333_f64", synth.ukdale_windows(6, 333, seed=12).astype(np.float64), seed=102, gain=2.0)
+    # 3. signed (shifted) input -> negative sigmoid arguments, states in {-1,-0,0,1} (quirk 8)
+    x = synth.ukdale_windows(6, 200, seed=13).astype(np.float64)
+    x = x - 2.0  # base load ~ -1.85: ma*x < -ln3 wherever the averaged CAM is high off-pulse
+    run_case("ensemble_l200_signed", x, seed=103, gain=2.0)
+    # 4. even moving-average window (asymmetric taps) + single window + 2 members
+    run_case("pair_l128_wma4", synth.ukdale_windows(4, 128, seed=14), seed=104, gain=2.0, w_ma=4, members=[7, 25])
+    # 5. the gated (device != cpu) variant of predict, quirk 7
+    run_case("ensemble_l160_gated", synth.ukdale_windows(10, 160, seed=15), seed=105, gain=2.0, gated=True)
+    # 6. all-zero input and constant input windows (cam.max()==0 style degenerate cases), short L
+    z = np.zeros((4, 64), np.float32)
+    z[1] = 0.5
+    z[2, 10:20] = 3.0
+    z[3] = synth.ukdale_windows(1, 64, seed=16)[0]
+    run_case("ensemble_l64_degenerate", z, seed=106, gain=2.0)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,91 @@
+"""CPU: the oracle (oracle/camal_oracle.py) against outputs of the reference itself.
+
+The .npz files hold what the reference's CamALResNet / CAM.run / CamAL.predict returned
+in the dev container (tests/golden/make_golden.py).  This pins the oracle; the GPU
+parity tests then compare the HIP path with the oracle and with the same fixtures.
+"""
+import numpy as np
+import pytest
+
+from oracle import camal_oracle as oracle
+from tests.helpers import REL_TOL_FP32, case_state_dicts, golden_cases, load_case, rel_err
+
+CASES = golden_cases("ensemble_") + golden_cases("pair_")
+
+
+def test_fixtures_present():
+    assert len(CASES) >= 6
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_members_match_reference(name):
+    c = load_case(name)
+    sds = case_state_dicts(c)
+    for e, sd in enumerate(sds):
+        cams, labels, probs = oracle.cam_batch(sd, c["data"], 1)
+        assert rel_err(cams, c["cams"][e]) < REL_TOL_FP32
+        assert np.abs(probs - c["probs"][e]).max() < REL_TOL_FP32
+        # labels may only differ where the probabilities tie to within rounding
+        diff = labels != c["labels"][e]
+        assert np.all(np.abs(c["probs"][e][diff, 1] - 0.5) < 1e-4)
+        logits = oracle.resnet_forward(sd, c["data"][:, None, :])
+        assert rel_err(logits.T, c["logits"][e].T) < REL_TOL_FP32
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_predict_matches_reference(name):
+    c = load_case(name)
+    sds = case_state_dicts(c)
+    states, prob, avg_cam, _ = oracle.camal_predict(
+        sds, c["data"], w_ma=int(c["w_ma"]), gated=bool(c["gated"]), return_intermediate=True)
+    assert states.dtype == c["states"].dtype and states.shape == c["states"].shape
+    assert np.abs(prob - c["prob_detect"]).max() < REL_TOL_FP32
+    assert np.abs(avg_cam - c["avg_cam"]).max() < REL_TOL_FP32
+    assert (states == c["states"]).mean() >= 0.999
+    # the signed case must contain the reference's negative states
+    if "signed" in name:
+        assert (c["states"] < 0).any()
+
+
+def test_loop_variant_equals_batched():
+    c = load_case("pair_l128_wma4")
+    sds = case_state_dicts(c)
+    s1, p1 = oracle.camal_predict(sds, c["data"], w_ma=4, return_prob=True)
+    s2, p2 = oracle.camal_predict_loop(sds, c["data"], w_ma=4)
+    assert np.array_equal(s1, s2) and np.allclose(p1, p2, atol=1e-6)
+
+
+def test_moving_average_taps():
+    # w=5 -> m in [t-2,t+2]; w=4 -> m in [t-2,t+1]; zeros outside [0,L)
+    x = np.arange(1.0, 11.0)
+    for w, lo, hi in ((5, -2, 2), (4, -2, 1), (3, -1, 1), (1, 0, 0)):
+        ref = np.array([sum(x[m] for m in range(t + lo, t + hi + 1) if 0 <= m < len(x)) / w
+                        for t in range(len(x))])
+        assert np.allclose(oracle.moving_average(x, w), ref)
+
+
+def test_state_threshold_is_ln3():
+    # 2*sigmoid(z)-1 rounds (half to even) to 1 iff z > ln 3
+    z = np.array([np.log(3.0) - 1e-9, np.log(3.0) + 1e-9, -np.log(3.0) - 1e-9, 0.0])
+    assert list(np.round(oracle.rectified_sigmoid(z))) == [0.0, 1.0, -1.0, 0.0]
+
+
+def test_power_clip():
+    states = np.array([[0.0, 1.0, 1.0, 1.0]])
+    x = np.array([[0.5, 0.1, 3.0, 2.0]])  # kW, scaler multiplies by 1000
+    p = oracle.power_estimate(states, x, 2000.0, scale_mul=1000.0)
+    assert np.allclose(p, [[0.0, 100.0, 2000.0, 2000.0]])
+
+
+def test_fold_bn_equivalence():
+    from camal_amd import weights
+    sd = weights.make_state_dict(7, seed=3)
+    x = np.random.default_rng(0).normal(size=(2, 64, 50)).astype(np.float32)
+    p = "layers.0.layers.1"
+    z = oracle.conv1d_replicate(x, sd[p + ".layers.0.weight"], sd[p + ".layers.0.bias"])
+    y = oracle.batchnorm_eval(z, sd[p + ".layers.1.weight"], sd[p + ".layers.1.bias"],
+                              sd[p + ".layers.1.running_mean"], sd[p + ".layers.1.running_var"])
+    w2, b2 = oracle.fold_bn(sd[p + ".layers.0.weight"], sd[p + ".layers.0.bias"], sd[p + ".layers.1.weight"],
+                            sd[p + ".layers.1.bias"], sd[p + ".layers.1.running_mean"], sd[p + ".layers.1.running_var"])
+    y2 = oracle.conv1d_replicate(x, w2, b2)
+    assert np.abs(y - y2).max() < 1e-5 * np.abs(y).max() + 1e-5
