@@ -1,0 +1,73 @@
+"""ctypes binding of libcamal_hip.so (C ABI: include/camal_hip.h).
+
+There is NO fallback: if the library is missing or a call fails, this raises.  The product
+path never routes through ``oracle/`` or any CPU restatement.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcamal_hip.so")
+
+FP32, BF16 = 0, 1
+PROF_CLASSES = ("stem", "conv", "conv_cam_head", "post", "other")
+
+
+class CamalHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_vp, _i, _d, _sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/camal_hip.h declares
+SIGNATURES = {
+    "camal_version": (C.c_char_p, []),
+    "camal_last_error": (C.c_char_p, []),
+    "camal_member_blob_floats": (_sz, [_i]),
+    "camal_create": (_i, [_i, _i, C.POINTER(_i), _i, C.POINTER(_vp)]),
+    "camal_destroy": (_i, [_vp]),
+    "camal_set_member_weights": (_i, [_vp, _i, C.POINTER(C.c_float), _sz]),
+    "camal_set_chunk_windows": (_i, [_vp, _i]),
+    "camal_forward_cam": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "camal_localize": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "camal_postprocess": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _vp, _vp, _vp, _vp, _vp]),
+    "camal_set_profiling": (_i, [_vp, _i]),
+    "camal_get_profile": (_i, [_vp, C.POINTER(_i), C.POINTER(_d)]),
+}
+
+
+def load():
+    """Load the library once; raises CamalHipError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CamalHipError(
+            f"{LIB_PATH} not found: build it first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C camal_amd/csrc).  camal_amd has no CPU fallback.")
+    # torch bundles its own libamdhip64 (same SONAME as the one hipcc links against).  Import it
+    # FIRST so that the loader binds this library to the runtime torch already initialised: two
+    # HIP runtimes in one process cannot share device pointers or streams.
+    import torch  # noqa: F401
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != 0:
+        msg = load().camal_last_error().decode("utf-8", "replace")
+        raise CamalHipError(f"libcamal_hip error {code}: {msg}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())

@@ -1,0 +1,455 @@
+// camal_hip.hip — host side of libcamal_hip.so: context, weight re-layout, launch sequences.
+// C ABI declared in include/camal_hip.h.  gfx950 only.
+#include "camal_kernels.hpp"
+#include "../../include/camal_hip.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace camal;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess)                                                                \
+            return fail(CAMAL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));   \
+    } while (0)
+
+constexpr int C1 = 64, C2 = 128;  // core.py:37 mid_channels default; CamAL.eval ignores kwargs (:386-390)
+constexpr int NT = 4;
+
+// The 9 ConvBlocks of one member: (Cin, Cout, k) with k<0 meaning "the member's kernel size".
+struct ConvShape { int cin, cout, k; };
+const ConvShape kConvs[9] = {{1, C1, -1},  {C1, C1, 7},  {C1, C1, 3},  {C1, C2, -1}, {C2, C2, 7},
+                             {C2, C2, 3},  {C2, C2, -1}, {C2, C2, 7},  {C2, C2, 3}};
+
+size_t blob_floats(int k) {
+    size_t n = 0;
+    for (const auto& c : kConvs) {
+        int kk = c.k < 0 ? k : c.k;
+        n += (size_t)c.cout * c.cin * kk + c.cout;
+    }
+    n += C1 * 1 + C1;      // residual 1
+    n += C2 * C1 + C2;     // residual 2
+    n += 2 * C2 + 2;       // head
+    return n;
+}
+
+struct Layer {
+    int cin = 0, cout = 0, ks = 0;
+    void* wpack = nullptr;   // [MT][ks][NCP][64][16 B]
+    float* bias = nullptr;   // [cout]
+};
+
+struct Member {
+    int k = 0;
+    bool loaded = false;
+    float *stem_w = nullptr, *stem_b = nullptr, *res1_w = nullptr, *res1_b = nullptr;
+    Layer conv[8];  // ConvBlocks 1..8 (ConvBlock 0 is the stem)
+    Layer res2;
+    float* wfc = nullptr;  // [2][128]
+    float* bfc = nullptr;  // [2]
+};
+
+struct ProfRec { int cls; hipEvent_t a, b; };
+
+}  // namespace
+
+struct camal_ctx {
+    int device = 0, E = 0, precision = 0, chunk = 256, cam_row = 1;
+    std::vector<Member> m;
+    std::vector<void*> owned;  // device allocations freed in destroy
+    // workspace
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    // profiling
+    bool prof = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;
+    size_t pool_used = 0;
+    int prof_launches[CAMAL_PROF_CLASSES] = {0};
+    double prof_ms[CAMAL_PROF_CLASSES] = {0};
+};
+
+namespace {
+
+int dev_alloc(camal_ctx* c, void** p, size_t bytes) {
+    HIP_TRY(hipMalloc(p, bytes));
+    c->owned.push_back(*p);
+    return 0;
+}
+
+int upload(camal_ctx* c, void** dst, const void* src, size_t bytes) {
+    if (int r = dev_alloc(c, dst, bytes)) return r;
+    HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+inline uint16_t f2bf(float f) {  // round to nearest even, NaN stays NaN
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1)) >> 16);
+}
+
+// w [cout][cin][ks] fp32 -> A-fragment order [mt][tap][chunk pair][lane][16 B]
+// fp32: lane (i = l&31, h = l>>5), element s  <-> W[32 mt + i][8 cp + 4 h + s][tap]
+// bf16: lane (i, h), element jj               <-> W[32 mt + i][16 cp + 8 h + jj][tap]
+std::vector<char> pack_weights(const float* w, int cout, int cin, int ks, int precision) {
+    const int kpp = precision == CAMAL_FP32 ? 8 : 16;
+    const int ncp = cin / kpp, mtn = cout / 32;
+    std::vector<char> out((size_t)mtn * ks * ncp * 1024);
+    for (int mt = 0; mt < mtn; ++mt)
+        for (int j = 0; j < ks; ++j)
+            for (int cp = 0; cp < ncp; ++cp)
+                for (int l = 0; l < 64; ++l) {
+                    char* dst = out.data() + ((((size_t)mt * ks + j) * ncp + cp) * 64 + l) * 16;
+                    const int co = 32 * mt + (l & 31), h = l >> 5;
+                    if (precision == CAMAL_FP32) {
+                        float v[4];
+                        for (int s = 0; s < 4; ++s) v[s] = w[((size_t)co * cin + 8 * cp + 4 * h + s) * ks + j];
+                        memcpy(dst, v, 16);
+                    } else {
+                        uint16_t v[8];
+                        for (int jj = 0; jj < 8; ++jj) v[jj] = f2bf(w[((size_t)co * cin + 16 * cp + 8 * h + jj) * ks + j]);
+                        memcpy(dst, v, 16);
+                    }
+                }
+    return out;
+}
+
+int make_layer(camal_ctx* c, Layer& ly, const float* w, const float* b, int cout, int cin, int ks) {
+    ly.cin = cin; ly.cout = cout; ly.ks = ks;
+    std::vector<char> p = pack_weights(w, cout, cin, ks, c->precision);
+    if (int r = upload(c, &ly.wpack, p.data(), p.size())) return r;
+    return upload(c, (void**)&ly.bias, b, cout * sizeof(float));
+}
+
+// ---- workspace ------------------------------------------------------------------------
+struct Workspace {
+    void *a1, *b1, *r1, *a2, *b2, *r2;
+    float *cam, *part, *logits;
+    int ntiles;
+};
+
+size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+size_t workspace_layout(const camal_ctx* c, int BC, int L, Workspace* w, char* base) {
+    const size_t es = c->precision == CAMAL_FP32 ? 4 : 2;
+    const size_t n64 = align_up((size_t)BC * L * C1 * es), n128 = align_up((size_t)BC * L * C2 * es);
+    const int ntiles = (L + 127) / 128;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += bytes; return (void*)p; };
+    Workspace t;
+    t.a1 = take(n64); t.b1 = take(n64); t.r1 = take(n64);
+    t.a2 = take(n128); t.b2 = take(n128); t.r2 = take(n128);
+    t.cam = (float*)take(align_up((size_t)c->E * BC * L * 4));
+    t.part = (float*)take(align_up((size_t)c->E * BC * ntiles * 2 * 4));
+    t.logits = (float*)take(align_up((size_t)c->E * BC * 2 * 4));
+    t.ntiles = ntiles;
+    if (w) *w = t;
+    return off;
+}
+
+int ensure_workspace(camal_ctx* c, int BC, int L, Workspace* w) {
+    size_t need = workspace_layout(c, BC, L, nullptr, nullptr);
+    if (need > c->ws_bytes) {
+        if (c->ws) HIP_TRY(hipFree(c->ws));
+        c->ws = nullptr; c->ws_bytes = 0;
+        hipError_t e = hipMalloc((void**)&c->ws, need);
+        if (e != hipSuccess) return fail(CAMAL_ERR_NOMEM, "workspace hipMalloc of " + std::to_string(need) + " bytes failed");
+        c->ws_bytes = need;
+    }
+    workspace_layout(c, BC, L, w, c->ws);
+    return 0;
+}
+
+// ---- profiling ------------------------------------------------------------------------
+struct ProfScope {
+    camal_ctx* c; hipStream_t s; ProfRec rec; bool on;
+    ProfScope(camal_ctx* ctx, hipStream_t st, int cls) : c(ctx), s(st), on(ctx && ctx->prof) {
+        if (!on) return;
+        while (c->pool.size() < c->pool_used + 2) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) { on = false; return; }
+            c->pool.push_back(e);
+        }
+        rec.cls = cls; rec.a = c->pool[c->pool_used++]; rec.b = c->pool[c->pool_used++];
+        (void)hipEventRecord(rec.a, s);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(rec.b, s);
+        c->recs.push_back(rec);
+    }
+};
+
+// ---- launches -------------------------------------------------------------------------
+template <typename DT, int CIN, int COUT, bool RELU, bool HAS_RES, bool HEAD>
+int launch_conv(camal_ctx* c, hipStream_t s, const Layer& ly, const void* in, const void* res, void* out,
+                const float* wfc, float* cam, float* part, int BC, int L) {
+    constexpr int MT = COUT / 32, NG = 4 / MT, TN = NG * NT * 32;
+    auto kern = conv_kernel<DT, CIN, COUT, NT, RELU, HAS_RES, HEAD>;
+    size_t lds = (size_t)(TN + ly.ks - 1) * CIN * sizeof(DT);
+    if (HEAD) lds = std::max(lds, (size_t)MT * TN * 2 * sizeof(float));
+    static size_t attr_set = 0;  // per instantiation
+    if (lds > attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = lds;
+    }
+    dim3 grid((L + TN - 1) / TN, BC);
+    ProfScope ps(c, s, HEAD ? 2 : 1);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const DT*)in, (const uint4*)ly.wpack, ly.bias, (const DT*)res,
+                       (DT*)out, wfc, cam, part, L, ly.ks, c->cam_row);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// One member's conv stack on BC windows: x -> cam row 1 [BC][L] + pooled partials [BC][ntiles][2]
+template <typename DT>
+int run_member(camal_ctx* c, hipStream_t s, const Member& m, const float* x, int BC, int L, const Workspace& w,
+               float* cam, float* part) {
+    {
+        ProfScope ps(c, s, 0);
+        hipLaunchKernelGGL(stem_kernel<DT>, dim3((L + 63) / 64, BC), dim3(256), 0, s, x, m.stem_w, m.stem_b, m.res1_w,
+                           m.res1_b, (DT*)w.a1, (DT*)w.r1, L, m.k);
+        HIP_TRY(hipGetLastError());
+    }
+    int r;
+    // block 1: ConvBlock(7), ConvBlock(3) + residual (camal_resnet.py:35-38,56-58)
+    if ((r = launch_conv<DT, C1, C1, true, false, false>(c, s, m.conv[0], w.a1, nullptr, w.b1, nullptr, nullptr, nullptr, BC, L))) return r;
+    if ((r = launch_conv<DT, C1, C1, true, true, false>(c, s, m.conv[1], w.b1, w.r1, w.a1, nullptr, nullptr, nullptr, BC, L))) return r;
+    // block 2: residual BN(Conv1x1) first (no ReLU), then ConvBlock(k), (7), (3)+residual
+    if ((r = launch_conv<DT, C1, C2, false, false, false>(c, s, m.res2, w.a1, nullptr, w.r2, nullptr, nullptr, nullptr, BC, L))) return r;
+    if ((r = launch_conv<DT, C1, C2, true, false, false>(c, s, m.conv[2], w.a1, nullptr, w.a2, nullptr, nullptr, nullptr, BC, L))) return r;
+    if ((r = launch_conv<DT, C2, C2, true, false, false>(c, s, m.conv[3], w.a2, nullptr, w.b2, nullptr, nullptr, nullptr, BC, L))) return r;
+    if ((r = launch_conv<DT, C2, C2, true, true, false>(c, s, m.conv[4], w.b2, w.r2, w.a2, nullptr, nullptr, nullptr, BC, L))) return r;
+    // block 3: no skip (camal_resnet.py:40-41,59); last ConvBlock fused with the CAM head
+    if ((r = launch_conv<DT, C2, C2, true, false, false>(c, s, m.conv[5], w.a2, nullptr, w.b2, nullptr, nullptr, nullptr, BC, L))) return r;
+    if ((r = launch_conv<DT, C2, C2, true, false, false>(c, s, m.conv[6], w.b2, nullptr, w.a2, nullptr, nullptr, nullptr, BC, L))) return r;
+    if ((r = launch_conv<DT, C2, C2, true, false, true>(c, s, m.conv[7], w.a2, nullptr, nullptr, m.wfc, cam, part, BC, L))) return r;
+    return 0;
+}
+
+int run_member_any(camal_ctx* c, hipStream_t s, const Member& m, const float* x, int BC, int L, const Workspace& w,
+                   float* cam, float* part, float* logits) {
+    int r = c->precision == CAMAL_FP32 ? run_member<float>(c, s, m, x, BC, L, w, cam, part)
+                                       : run_member<__bf16>(c, s, m, x, BC, L, w, cam, part);
+    if (r) return r;
+    ProfScope ps(c, s, 4);
+    hipLaunchKernelGGL(logits_kernel, dim3((BC + 127) / 128), dim3(128), 0, s, part, m.bfc, logits, BC, w.ntiles, L);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int check_ctx(camal_ctx* c, int B, int L) {
+    if (!c) return fail(CAMAL_ERR_ARG, "null context");
+    if (B < 1 || L < 1) return fail(CAMAL_ERR_ARG, "B and L must be >= 1");
+    for (int e = 0; e < c->E; ++e)
+        if (!c->m[e].loaded) return fail(CAMAL_ERR_STATE, "member " + std::to_string(e) + " has no weights");
+    HIP_TRY(hipSetDevice(c->device));
+    return 0;
+}
+
+int launch_post(camal_ctx* c, hipStream_t s, const PostArgs& a) {
+    ProfScope ps(c, s, 3);
+    hipLaunchKernelGGL(post_kernel, dim3(a.B), dim3(256), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* camal_version(void) { return "camal_hip 1 gfx950"; }
+const char* camal_last_error(void) { return g_err.c_str(); }
+size_t camal_member_blob_floats(int kernel_size) { return blob_floats(kernel_size); }
+
+int camal_create(int device_id, int n_members, const int* kernel_sizes, int precision, camal_ctx** out) {
+    if (!out || !kernel_sizes) return fail(CAMAL_ERR_ARG, "null argument");
+    if (n_members < 1 || n_members > CAMAL_MAX_MEMBERS) return fail(CAMAL_ERR_ARG, "n_members must be in 1..16");
+    if (precision != CAMAL_FP32 && precision != CAMAL_BF16) return fail(CAMAL_ERR_ARG, "precision must be 0 (fp32) or 1 (bf16)");
+    for (int e = 0; e < n_members; ++e)
+        if (kernel_sizes[e] < 1 || kernel_sizes[e] > 63 || !(kernel_sizes[e] & 1))
+            return fail(CAMAL_ERR_ARG, "kernel sizes must be odd and in 1..63");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(CAMAL_ERR_ARG, "no such device");
+    HIP_TRY(hipSetDevice(device_id));
+    camal_ctx* c = new camal_ctx();
+    c->device = device_id; c->E = n_members; c->precision = precision;
+    c->m.resize(n_members);
+    for (int e = 0; e < n_members; ++e) c->m[e].k = kernel_sizes[e];
+    *out = c;
+    return 0;
+}
+
+int camal_destroy(camal_ctx* c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : c->owned) (void)hipFree(p);
+    if (c->ws) (void)hipFree(c->ws);
+    for (hipEvent_t e : c->pool) (void)hipEventDestroy(e);
+    delete c;
+    return 0;
+}
+
+int camal_set_chunk_windows(camal_ctx* c, int windows) {
+    if (!c || windows < 1) return fail(CAMAL_ERR_ARG, "chunk windows must be >= 1");
+    c->chunk = windows;
+    return 0;
+}
+
+int camal_set_member_weights(camal_ctx* c, int member, const float* f, size_t n_floats) {
+    if (!c || !f) return fail(CAMAL_ERR_ARG, "null argument");
+    if (member < 0 || member >= c->E) return fail(CAMAL_ERR_ARG, "member index out of range");
+    Member& m = c->m[member];
+    if (m.loaded) return fail(CAMAL_ERR_STATE, "member weights already set (create a new context to replace them)");
+    if (n_floats != blob_floats(m.k))
+        return fail(CAMAL_ERR_ARG, "blob has " + std::to_string(n_floats) + " floats, expected " + std::to_string(blob_floats(m.k)));
+    HIP_TRY(hipSetDevice(c->device));
+    const float* p = f;
+    int r;
+    for (int i = 0; i < 9; ++i) {
+        const int cin = kConvs[i].cin, cout = kConvs[i].cout, ks = kConvs[i].k < 0 ? m.k : kConvs[i].k;
+        const float* w = p; p += (size_t)cout * cin * ks;
+        const float* b = p; p += cout;
+        if (i == 0) {  // stem: [64][1][k] -> [k][64]
+            std::vector<float> t((size_t)ks * C1);
+            for (int co = 0; co < C1; ++co)
+                for (int j = 0; j < ks; ++j) t[(size_t)j * C1 + co] = w[(size_t)co * ks + j];
+            if ((r = upload(c, (void**)&m.stem_w, t.data(), t.size() * 4))) return r;
+            if ((r = upload(c, (void**)&m.stem_b, b, C1 * 4))) return r;
+        } else if ((r = make_layer(c, m.conv[i - 1], w, b, cout, cin, ks))) return r;
+    }
+    if ((r = upload(c, (void**)&m.res1_w, p, C1 * 4))) return r;
+    p += C1;
+    if ((r = upload(c, (void**)&m.res1_b, p, C1 * 4))) return r;
+    p += C1;
+    if ((r = make_layer(c, m.res2, p, p + (size_t)C2 * C1, C2, C1, 1))) return r;
+    p += (size_t)C2 * C1 + C2;
+    if ((r = upload(c, (void**)&m.wfc, p, 2 * C2 * 4))) return r;
+    p += 2 * C2;
+    if ((r = upload(c, (void**)&m.bfc, p, 2 * 4))) return r;
+    m.loaded = true;
+    return 0;
+}
+
+int camal_forward_cam(camal_ctx* c, const float* x, int B, int L, int member, int cam_label, float* logits, float* cam,
+                      void* stream) {
+    if (int r = check_ctx(c, B, L)) return r;
+    if (cam_label != 0 && cam_label != 1) return fail(CAMAL_ERR_ARG, "cam_label must be 0 or 1");
+    c->cam_row = cam_label;
+    if (!x || !logits) return fail(CAMAL_ERR_ARG, "x_dev and logits_dev are required");
+    if (member < -1 || member >= c->E) return fail(CAMAL_ERR_ARG, "member index out of range");
+    hipStream_t s = (hipStream_t)stream;
+    const int BC = std::min(B, c->chunk);
+    Workspace w;
+    if (int r = ensure_workspace(c, BC, L, &w)) return r;
+    const int e0 = member < 0 ? 0 : member, e1 = member < 0 ? c->E : member + 1, EO = e1 - e0;
+    for (int c0 = 0; c0 < B; c0 += BC) {
+        const int n = std::min(BC, B - c0);
+        for (int e = e0; e < e1; ++e) {
+            float* camw = w.cam;  // member rows are consumed immediately: one row buffer is enough
+            if (int r = run_member_any(c, s, c->m[e], x + (size_t)c0 * L, n, L, w, camw, w.part, w.logits)) return r;
+            HIP_TRY(hipMemcpyAsync(logits + ((size_t)(e - e0) * B + c0) * 2, w.logits, (size_t)n * 2 * 4, hipMemcpyDeviceToDevice, s));
+            if (cam) HIP_TRY(hipMemcpyAsync(cam + ((size_t)(e - e0) * B + c0) * L, camw, (size_t)n * L * 4, hipMemcpyDeviceToDevice, s));
+        }
+    }
+    (void)EO;
+    return 0;
+}
+
+int camal_postprocess(int E, const float* cam, const float* logits, const float* x, const double* x64, const int8_t* y,
+                      int B, int L, int w_ma, int gate_mode, int pred_f64, double p_on, double scale_mul,
+                      double scale_add, double* prob_out, float* avg_cam_out, float* state_out, float* power_out,
+                      void* stream) {
+    if (E < 1 || E > CAMAL_MAX_MEMBERS) return fail(CAMAL_ERR_ARG, "n_members must be in 1..16");
+    if (!cam || !logits || !x || !prob_out || !state_out) return fail(CAMAL_ERR_ARG, "null argument");
+    if (B < 1 || L < 1) return fail(CAMAL_ERR_ARG, "B and L must be >= 1");
+    if (w_ma < 1 || w_ma > 64) return fail(CAMAL_ERR_ARG, "w_ma must be in 1..64");
+    PostArgs a;
+    a.cam = cam; a.logits = logits; a.x = x; a.x64 = x64; a.y = y;
+    a.prob_out = prob_out; a.avg_out = avg_cam_out; a.state_out = state_out; a.power_out = power_out;
+    a.E = E; a.B = B; a.L = L; a.w_ma = w_ma; a.gate_mode = gate_mode; a.pred_f64 = pred_f64;
+    a.p_on = p_on; a.scale_mul = scale_mul; a.scale_add = scale_add;
+    return launch_post(nullptr, (hipStream_t)stream, a);
+}
+
+int camal_localize(camal_ctx* c, const float* x, const double* x64, const int8_t* y, int B, int L, int w_ma,
+                   int gate_mode, int pred_f64, double p_on, double scale_mul, double scale_add, double* prob_out,
+                   float* avg_cam_out, float* state_out, float* power_out, float* member_logits_out,
+                   float* member_cam_out, void* stream) {
+    if (int r = check_ctx(c, B, L)) return r;
+    if (!x || !prob_out || !state_out) return fail(CAMAL_ERR_ARG, "x_dev, prob_out and state_out are required");
+    if (w_ma < 1 || w_ma > 64) return fail(CAMAL_ERR_ARG, "w_ma must be in 1..64");
+    if (gate_mode != 0 && gate_mode != 1) return fail(CAMAL_ERR_ARG, "gate_mode must be 0 or 1");
+    hipStream_t s = (hipStream_t)stream;
+    c->cam_row = 1;  // core.py:302-303 always asks for the CAM of label 1
+    const int BC = std::min(B, c->chunk), E = c->E;
+    Workspace w;
+    if (int r = ensure_workspace(c, BC, L, &w)) return r;
+    for (int c0 = 0; c0 < B; c0 += BC) {
+        const int n = std::min(BC, B - c0);
+        for (int e = 0; e < E; ++e) {
+            // chunk-local layout [E][n][..] so that the post kernel's member stride is n*L
+            float* camw = w.cam + (size_t)e * n * L;
+            float* lgw = w.logits + (size_t)e * n * 2;
+            float* partw = w.part + (size_t)e * n * w.ntiles * 2;
+            if (int r = run_member_any(c, s, c->m[e], x + (size_t)c0 * L, n, L, w, camw, partw, lgw)) return r;
+            if (member_logits_out)
+                HIP_TRY(hipMemcpyAsync(member_logits_out + ((size_t)e * B + c0) * 2, lgw, (size_t)n * 2 * 4, hipMemcpyDeviceToDevice, s));
+            if (member_cam_out)
+                HIP_TRY(hipMemcpyAsync(member_cam_out + ((size_t)e * B + c0) * L, camw, (size_t)n * L * 4, hipMemcpyDeviceToDevice, s));
+        }
+        PostArgs a;
+        a.cam = w.cam; a.logits = w.logits; a.x = x + (size_t)c0 * L; a.x64 = x64 ? x64 + (size_t)c0 * L : nullptr;
+        a.y = y ? y + c0 : nullptr;
+        a.prob_out = prob_out + c0; a.avg_out = avg_cam_out ? avg_cam_out + (size_t)c0 * L : nullptr;
+        a.state_out = state_out + (size_t)c0 * L; a.power_out = power_out ? power_out + (size_t)c0 * L : nullptr;
+        a.E = E; a.B = n; a.L = L; a.w_ma = w_ma; a.gate_mode = gate_mode; a.pred_f64 = pred_f64;
+        a.p_on = p_on; a.scale_mul = scale_mul; a.scale_add = scale_add;
+        if (int r = launch_post(c, s, a)) return r;
+    }
+    return 0;
+}
+
+int camal_set_profiling(camal_ctx* c, int enabled) {
+    if (!c) return fail(CAMAL_ERR_ARG, "null context");
+    c->prof = enabled != 0;
+    c->recs.clear();
+    c->pool_used = 0;
+    for (int i = 0; i < CAMAL_PROF_CLASSES; ++i) { c->prof_launches[i] = 0; c->prof_ms[i] = 0; }
+    return 0;
+}
+
+int camal_get_profile(camal_ctx* c, int* launches, double* ms) {
+    if (!c || !launches || !ms) return fail(CAMAL_ERR_ARG, "null argument");
+    for (const ProfRec& r : c->recs) {
+        HIP_TRY(hipEventSynchronize(r.b));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
+        c->prof_launches[r.cls] += 1;
+        c->prof_ms[r.cls] += t;
+    }
+    c->recs.clear();
+    c->pool_used = 0;
+    for (int i = 0; i < CAMAL_PROF_CLASSES; ++i) { launches[i] = c->prof_launches[i]; ms[i] = c->prof_ms[i]; }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,443 @@
+// camal_kernels.hpp — gfx950 (CDNA4) device code for the CamAL inference path.
+//
+// Data layout in HBM:
+//   activations  [window][time][channel]   (channels-last; 16-byte chunks of 4 fp32 / 8 bf16
+//                                            channels are the unit every load/store moves)
+//   conv weights  packed per layer in MFMA A-fragment order
+//                 [m-tile of 32 out-channels][tap][chunk-pair][lane 0..63][16 bytes]
+//   CAM rows      [member][window][time] fp32, pooled partial sums [member][window][tile][2]
+//
+// Implicit GEMM view of one ConvBlock (reference camal_resnet.py:81-86, BN folded):
+//   D[co][t] = sum_{tap j} sum_{ci} W'[co][ci][j] * X[clamp(t + j - k/2)][ci]
+//   M = out-channels (MFMA rows), N = time (MFMA columns, one column per lane),
+//   K = (tap, in-channel).  The time tile plus its k-1 halo rows is staged once into LDS
+//   (replicate padding = clamping the staged row's source position, per layer, exactly as
+//   the reference pads each layer's own input), and every tap re-reads it at a row offset.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace camal {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <typename DT> struct Elem;
+template <> struct Elem<float> { static constexpr int PER_CHUNK = 4; static constexpr int K_PER_PAIR = 8; };
+template <> struct Elem<__bf16> { static constexpr int PER_CHUNK = 8; static constexpr int K_PER_PAIR = 16; };
+
+// XOR swizzle of the 16-byte chunk index inside an LDS row so that the 16 lanes of one
+// ds_read_b128 group (rows distinct mod 16, same logical chunk) hit 16 different slots of
+// the 256-byte bank row.  Rows of 128 B hold two rows per bank row, hence the shift.
+template <int CHUNKS_PER_ROW> __device__ __forceinline__ int swz(int row) {
+    if (CHUNKS_PER_ROW >= 16) return row & 15;
+    return (row >> 1) & 7;
+}
+
+__device__ __forceinline__ void mma_chunk(const uint4& a, const uint4& b, f32x16& acc, float) {
+    // fp32: 4 k-steps of v_mfma_f32_32x32x2_f32; lane half h carries k = h.
+    const float* af = reinterpret_cast<const float*>(&a);
+    const float* bf = reinterpret_cast<const float*>(&b);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bf[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bf[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2], bf[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], bf[3], acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_chunk(const uint4& a, const uint4& b, f32x16& acc, __bf16) {
+    // bf16: one v_mfma_f32_32x32x16_bf16; lane half h carries k = 8h..8h+7.
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a),
+                                                  *reinterpret_cast<const bf16x8*>(&b), acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+__device__ __forceinline__ void store4(__bf16* p, float a, float b, float c, float d) {
+    bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+    *reinterpret_cast<bf16x4*>(p) = v;
+}
+__device__ __forceinline__ void load4(const float* p, float (&v)[4]) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void load4(const __bf16* p, float (&v)[4]) {
+    bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+    v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+}
+
+// ---------------------------------------------------------------------------------------
+// Stem: the Cin = 1 layers of block 1 on the VALU (K = k <= 63 is not MFMA-shaped).
+//   a1[t][co] = relu(b'[co] + sum_j w'[co][j] * x[clamp(t + j - k/2)])   (camal_resnet.py:14, ConvBlock 0)
+//   r1[t][co] = wr'[co] * x[t] + br'[co]                                  (residual, :51-54)
+// One workgroup = 64 timesteps x 64 channels; thread = 4 channels x 4 timesteps.
+// ---------------------------------------------------------------------------------------
+template <typename DT>
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x,      // [B][L]
+                                                   const float* __restrict__ w,      // [ks][64]
+                                                   const float* __restrict__ bias,   // [64]
+                                                   const float* __restrict__ wr,     // [64]
+                                                   const float* __restrict__ br,     // [64]
+                                                   DT* __restrict__ a1, DT* __restrict__ r1,  // [B][L][64]
+                                                   int L, int ks) {
+    __shared__ float xs[64 + 64];
+    const int b = blockIdx.y, t0 = blockIdx.x * 64, pad = ks >> 1;
+    const float* xb = x + (size_t)b * L;
+    for (int i = threadIdx.x; i < 64 + ks - 1; i += 256) {
+        int p = t0 - pad + i;
+        p = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
+        xs[i] = xb[p];
+    }
+    __syncthreads();
+    const int cg = threadIdx.x & 15, tq = threadIdx.x >> 4;  // 16 channel groups x 16 time slots
+    float acc[4][4];
+    float bv[4], wrv[4], brv[4];
+    load4(bias + 4 * cg, bv); load4(wr + 4 * cg, wrv); load4(br + 4 * cg, brv);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[q][c] = bv[c];
+    for (int j = 0; j < ks; ++j) {
+        float wv[4];
+        load4(w + j * 64 + 4 * cg, wv);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float xv = xs[tq + 16 * q + j];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[q][c] = fmaf(wv[c], xv, acc[q][c]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int t = t0 + tq + 16 * q;
+        if (t < L) {
+            size_t o = ((size_t)b * L + t) * 64 + 4 * cg;
+            store4(a1 + o, fmaxf(acc[q][0], 0.f), fmaxf(acc[q][1], 0.f), fmaxf(acc[q][2], 0.f), fmaxf(acc[q][3], 0.f));
+            float xv = xs[tq + 16 * q + pad];
+            store4(r1 + o, fmaf(wrv[0], xv, brv[0]), fmaf(wrv[1], xv, brv[1]), fmaf(wrv[2], xv, brv[2]),
+                   fmaf(wrv[3], xv, brv[3]));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Implicit-GEMM Conv1d(replicate) + folded BN + [ReLU] + [residual add] on MFMA.
+// 4 waves; wave w owns out-channel tile (w % MT) and NT column tiles of 32 timesteps.
+//   HEAD = false: writes out[b][t][co]   (+ res[b][t][co] added AFTER the ReLU, :56-59)
+//   HEAD = true : last ConvBlock; the 128 x L feature map is never written.  Emits the two
+//                 CAM rows' values W_fc[k] . relu(.) per timestep: cam[b][t] for k = 1
+//                 (class_activation_map.py:42-48) and per-tile sums over t of both rows
+//                 (mean_t(W_fc[k].F) + b_k == Linear(mean_t F), camal_resnet.py:23).
+// ---------------------------------------------------------------------------------------
+template <typename DT, int CIN, int COUT, int NT, bool RELU, bool HAS_RES, bool HEAD>
+__global__ __launch_bounds__(256, 2) void conv_kernel(const DT* __restrict__ in,     // [B][L][CIN]
+                                                      const uint4* __restrict__ wpack,
+                                                      const float* __restrict__ bias,  // [COUT]
+                                                      const DT* __restrict__ res,    // [B][L][COUT]
+                                                      DT* __restrict__ out,          // [B][L][COUT]
+                                                      const float* __restrict__ wfc, // [2][COUT]
+                                                      float* __restrict__ cam_out,   // [B][L]
+                                                      float* __restrict__ part_out,  // [B][gridDim.x][2]
+                                                      int L, int ks, int cam_row) {
+    constexpr int ES = sizeof(DT);
+    constexpr int RB = CIN * ES;                 // LDS row bytes
+    constexpr int CPR = RB / 16;                 // 16-byte chunks per row
+    constexpr int NCP = CIN / Elem<DT>::K_PER_PAIR;  // chunk pairs per tap
+    constexpr int MT = COUT / 32;                // out-channel tiles
+    constexpr int NG = 4 / MT;                   // column groups across waves
+    constexpr int TN = NG * NT * 32;             // timesteps per workgroup
+    static_assert(MT == 2 || MT == 4, "COUT must be 64 or 128");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mt = wave % MT, ng = wave / MT;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y, t0 = blockIdx.x * TN, pad = ks >> 1;
+    const int TR = TN + ks - 1;
+
+    // ---- stage the input tile (+halo) into LDS, clamped = replicate padding of THIS layer
+    {
+        const char* inb = reinterpret_cast<const char*>(in + (size_t)b * L * CIN);
+        const int nchunks = TR * CPR;
+        for (int q = threadIdx.x; q < nchunks; q += 256) {
+            int row = q / CPR, c = q % CPR;
+            int p = t0 - pad + row;
+            p = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
+            uint4 v = *reinterpret_cast<const uint4*>(inb + (size_t)p * RB + c * 16);
+            *reinterpret_cast<uint4*>(lds + row * RB + ((c ^ swz<CPR>(row)) << 4)) = v;
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+
+    // ---- K loop: taps x chunk pairs.  A fragment (weights) streams from L2 in packed
+    //      order, one coalesced 1 KiB read per wave and chunk pair, prefetched one ahead.
+    const uint4* wp = wpack + (size_t)mt * ks * NCP * 64 + lane;
+    const int total = ks * NCP;
+    const int R0 = ng * NT * 32 + r;
+    uint4 a_cur = wp[0];
+    for (int j = 0; j < ks; ++j) {
+        const int row = R0 + j;
+        const int s = swz<CPR>(row);
+        const char* rowp = lds + row * RB;
+#pragma unroll
+        for (int cp = 0; cp < NCP; ++cp) {
+            int idx = j * NCP + cp + 1;
+            idx = idx < total ? idx : total - 1;
+            uint4 a_nxt = wp[(size_t)idx * 64];
+            const int col = ((2 * cp + h) ^ s) << 4;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                uint4 bv = *reinterpret_cast<const uint4*>(rowp + nt * 32 * RB + col);
+                mma_chunk(a_cur, bv, acc[nt], DT());
+            }
+            a_cur = a_nxt;
+        }
+    }
+
+    // ---- epilogue.  acc[nt][reg]: column t = tile + r, row co = 32 mt + (reg&3) + 8 (reg>>2) + 4 h
+    if constexpr (!HEAD) {
+        float bv[4][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) load4(bias + 32 * mt + 8 * g + 4 * h, bv[g]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int t = t0 + (ng * NT + nt) * 32 + r;
+            if (t < L) {
+                const size_t o = ((size_t)b * L + t) * COUT + 32 * mt + 4 * h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        v[i] = acc[nt][4 * g + i] + bv[g][i];
+                        if (RELU) v[i] = fmaxf(v[i], 0.f);
+                    }
+                    if constexpr (HAS_RES) {
+                        float rv[4];
+                        load4(res + o + 8 * g, rv);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] += rv[i];
+                    }
+                    store4(out + o + 8 * g, v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    } else {
+        float bv[4][4], w0[4][4], w1[4][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            load4(bias + 32 * mt + 8 * g + 4 * h, bv[g]);
+            load4(wfc + 32 * mt + 8 * g + 4 * h, w0[g]);
+            load4(wfc + COUT + 32 * mt + 8 * g + 4 * h, w1[g]);
+        }
+        __syncthreads();  // every wave is done reading the activation tile: reuse LDS
+        float* red = reinterpret_cast<float*>(lds);  // [MT][TN][2]
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float c0 = 0.f, c1 = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float f = fmaxf(acc[nt][4 * g + i] + bv[g][i], 0.f);
+                    c0 = fmaf(w0[g][i], f, c0);
+                    c1 = fmaf(w1[g][i], f, c1);
+                }
+            c0 += __shfl_xor(c0, 32);
+            c1 += __shfl_xor(c1, 32);
+            if (h == 0) {
+                const int tl = (ng * NT + nt) * 32 + r;
+                red[(mt * TN + tl) * 2 + 0] = c0;
+                red[(mt * TN + tl) * 2 + 1] = c1;
+            }
+        }
+        __syncthreads();
+        float s0 = 0.f, s1 = 0.f;
+        for (int tl = threadIdx.x; tl < TN; tl += 256) {
+            float c0 = 0.f, c1 = 0.f;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                c0 += red[(m * TN + tl) * 2 + 0];
+                c1 += red[(m * TN + tl) * 2 + 1];
+            }
+            const int t = t0 + tl;
+            if (t < L) {
+                cam_out[(size_t)b * L + t] = cam_row ? c1 : c0;
+                s0 += c0;
+                s1 += c1;
+            }
+        }
+        // block sum of (s0, s1): wave shuffle tree, then 4 partials through LDS
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s0 += __shfl_xor(s0, o);
+            s1 += __shfl_xor(s1, o);
+        }
+        __syncthreads();
+        if (lane == 0) { red[2 * wave] = s0; red[2 * wave + 1] = s1; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float* po = part_out + ((size_t)b * gridDim.x + blockIdx.x) * 2;
+            po[0] = (red[0] + red[2]) + (red[4] + red[6]);
+            po[1] = (red[1] + red[3]) + (red[5] + red[7]);
+        }
+    }
+}
+
+// logits[b][k] = (sum over tiles of part[b][tile][k]) / L + b_fc[k]   (camal_resnet.py:23)
+__device__ __forceinline__ void member_logits(const float* part, int ntiles, int L, const float* bfc, float& l0,
+                                              float& l1) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = 0; i < ntiles; ++i) { s0 += part[2 * i]; s1 += part[2 * i + 1]; }
+    l0 = s0 / (float)L + bfc[0];
+    l1 = s1 / (float)L + bfc[1];
+}
+
+__global__ void logits_kernel(const float* __restrict__ part, const float* __restrict__ bfc,
+                              float* __restrict__ logits, int B, int ntiles, int L) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float l0, l1;
+    member_logits(part + (size_t)b * ntiles * 2, ntiles, L, bfc, l0, l1);
+    logits[2 * b] = l0;
+    logits[2 * b + 1] = l1;
+}
+
+// ---------------------------------------------------------------------------------------
+// Fused ensemble post-processing, one workgroup per window (HBM-bound: reads E CAM rows +
+// the aggregate, writes states [+ power, + average CAM]).  Restates, in the reference's
+// order and precisions:
+//   core.py:305      prob += softmax(logits)[1]             (float32 softmax, float64 sum)
+//   core.py:308-317  if argmax==1: c = clip(cam,0); nan/inf->0; if max(c)>0: pred += c/max(c)
+//   core.py:320-324  prob/=E; pred/=E; pred *= round_half_even(prob)
+//   core.py:429-437  ma = convolve(pred, ones(w),'same')/w; s = 2/(1+exp(-ma*x))-1; round(s)
+//   core.py:216-218  power = min(int(state)*p_on, x*scale_mul+scale_add)
+// ---------------------------------------------------------------------------------------
+#define CAMAL_MAX_MEMBERS 16
+#define POST_TILE 1024
+
+struct PostArgs {
+    const float* cam;      // [E][B][L]
+    const float* logits;   // [E][B][2]
+    const float* x;        // [B][L]
+    const double* x64;     // [B][L] or null
+    const int8_t* y;       // [B] or null
+    double* prob_out;      // [B]
+    float* avg_out;        // [B][L] or null
+    float* state_out;      // [B][L]
+    float* power_out;      // [B][L] or null
+    int E, B, L, w_ma, gate_mode, pred_f64;
+    double p_on, scale_mul, scale_add;
+};
+
+__device__ __forceinline__ float clip_cam(float v) {
+    v = v > 0.f ? v : 0.f;           // np.clip(a_min=0); NaN compares false -> 0 (nan_to_num)
+    return isinf(v) ? 0.f : v;       // posinf -> 0
+}
+
+__global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
+    __shared__ float s_max[CAMAL_MAX_MEMBERS];
+    __shared__ int s_lab[CAMAL_MAX_MEMBERS];
+    __shared__ double s_prob;
+    __shared__ float s_red[4];
+    __shared__ double s_pred[POST_TILE + 64];
+    const int b = blockIdx.x, L = a.L, E = a.E;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    if (threadIdx.x == 0) {
+        double psum = 0.0;
+        bool skip = false;
+        if (a.y) skip = a.y[b] < 1;
+        for (int e = 0; e < E; ++e) {
+            const float* lg = a.logits + ((size_t)e * a.B + b) * 2;
+            float l0 = lg[0], l1 = lg[1];
+            float m = fmaxf(l0, l1);
+            float e0 = expf(l0 - m), e1 = expf(l1 - m);
+            float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
+            int lab = p1 > p0 ? 1 : 0;
+            if (e == 0 && !a.y && a.gate_mode == 1) skip = lab < 1;
+            s_lab[e] = lab;
+            psum += (double)p1;
+        }
+        if (skip) {
+            psum = 0.0;
+            for (int e = 0; e < E; ++e) s_lab[e] = 0;
+        }
+        s_prob = psum / (double)E;
+    }
+    __syncthreads();
+    const double prob = s_prob;
+    const double vote = rint(prob);  // np.round: half to even
+    if (threadIdx.x == 0) a.prob_out[b] = prob;
+
+    // per-member max of the clipped CAM (only members that voted 'on', only if the window passes)
+    for (int e = 0; e < E; ++e) {
+        if (!s_lab[e] || vote == 0.0) { if (threadIdx.x == 0) s_max[e] = 0.f; continue; }
+        const float* c = a.cam + ((size_t)e * a.B + b) * L;
+        float m = 0.f;
+        for (int t = threadIdx.x; t < L; t += 256) m = fmaxf(m, clip_cam(c[t]));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        __syncthreads();
+        if (lane == 0) s_red[wave] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) s_max[e] = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    }
+    __syncthreads();
+
+    // np.convolve(x, ones(w), 'same')[t] = sum_{m = t + hi - w + 1 .. t + hi} x[m], hi = (w-1)/2
+    const int w = a.w_ma, hi = (w - 1) / 2, lo = hi - w + 1;  // lo <= 0
+    const float* xb = a.x + (size_t)b * L;
+    for (int c0 = 0; c0 < L; c0 += POST_TILE) {
+        const int n = min(POST_TILE, L - c0);
+        // pred for positions [c0 + lo, c0 + n + hi)
+        for (int i = threadIdx.x; i < n + hi - lo; i += 256) {
+            const int t = c0 + lo + i;
+            double pv = 0.0;
+            if (t >= 0 && t < L && vote != 0.0) {
+                if (a.pred_f64) {
+                    double acc = 0.0;
+                    for (int e = 0; e < E; ++e)
+                        if (s_max[e] > 0.f) acc += (double)(clip_cam(a.cam[((size_t)e * a.B + b) * L + t]) / s_max[e]);
+                    pv = acc / (double)E;
+                } else {
+                    float acc = 0.f;
+                    for (int e = 0; e < E; ++e)
+                        if (s_max[e] > 0.f) acc += clip_cam(a.cam[((size_t)e * a.B + b) * L + t]) / s_max[e];
+                    pv = (double)(acc / (float)E);
+                }
+                pv = pv * vote;
+            }
+            s_pred[i] = pv;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int t = c0 + i;
+            double sum = 0.0;
+            for (int m = 0; m < w; ++m) sum += s_pred[i + m];
+            const double ma = sum / (double)w;
+            const double xv = a.x64 ? a.x64[(size_t)b * L + t] : (double)xb[t];
+            const double z = ma * xv;
+            const double sg = 2.0 * (1.0 / (1.0 + exp(-z))) - 1.0;
+            const double st = rint(sg);
+            a.state_out[(size_t)b * L + t] = (float)st;
+            if (a.avg_out) a.avg_out[(size_t)b * L + t] = (float)s_pred[i - lo];
+            if (a.power_out) {
+                const double agg = xv * a.scale_mul + a.scale_add;
+                double yh = (double)(long long)st * a.p_on;
+                if (yh > agg) yh = agg;
+                a.power_out[(size_t)b * L + t] = (float)yh;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace camal

@@ -1,0 +1,167 @@
+"""Device-side ensemble: owns one ``camal_ctx`` (packed weights + workspace) per GPU.
+
+Torch is used only as the device-memory / stream provider: tensors' ``data_ptr()`` and the
+current HIP stream are handed to the C ABI (include/camal_hip.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, weights
+
+
+def folded_blob(sd) -> np.ndarray:
+    """State dict (reference key names) -> the float32 blob ``camal_set_member_weights`` takes.
+
+    BatchNorm (eval) is folded into each conv here, in float64; order documented
+    in include/camal_hip.h.
+    """
+    sd = weights.to_numpy_state_dict(sd)
+    k = weights.kernel_size_of(sd)
+    w0 = sd["layers.0.layers.0.layers.0.weight"]
+    if w0.shape[0] != 64 or w0.shape[1] != 1 or sd["linear.weight"].shape != (2, 128):
+        raise NotImplementedError(
+            "the HIP inference path implements the widths CamAL.eval() instantiates "
+            "(in_channels=1, mid_channels=64, nb_class=2; reference core.py:386-390)")
+    parts = []
+    for prefix, _ci, _co, _k in weights.conv_layers(k):
+        w, b = weights.fold_conv_bn(
+            sd[prefix + ".layers.0.weight"], sd[prefix + ".layers.0.bias"],
+            sd[prefix + ".layers.1.weight"], sd[prefix + ".layers.1.bias"],
+            sd[prefix + ".layers.1.running_mean"], sd[prefix + ".layers.1.running_var"])
+        parts += [w.ravel(), b.ravel()]
+    for prefix, _ci, _co in weights.residual_layers():
+        w, b = weights.fold_conv_bn(
+            sd[prefix + ".0.weight"], sd[prefix + ".0.bias"],
+            sd[prefix + ".1.weight"], sd[prefix + ".1.bias"],
+            sd[prefix + ".1.running_mean"], sd[prefix + ".1.running_var"])
+        parts += [w.ravel(), b.ravel()]
+    parts += [np.asarray(sd["linear.weight"], np.float32).ravel(), np.asarray(sd["linear.bias"], np.float32).ravel()]
+    return np.ascontiguousarray(np.concatenate(parts), dtype=np.float32)
+
+
+def _device_index(device) -> int:
+    d = torch.device(device)
+    if d.type != "cuda":
+        raise _lib.CamalHipError(
+            f"camal_amd runs on MI355X only (device={device!r}); there is no CPU path. "
+            "Use device='cuda' / 'cuda:N'.")
+    return d.index if d.index is not None else torch.cuda.current_device()
+
+
+class Ensemble:
+    """E ResNet members resident on one GPU."""
+
+    def __init__(self, state_dicts, device="cuda", precision="fp32", chunk_windows=None):
+        self.lib = _lib.load()
+        self.dev_index = _device_index(device)
+        self.device = torch.device("cuda", self.dev_index)
+        self.precision = {"fp32": _lib.FP32, "bf16": _lib.BF16}[precision]
+        self.precision_name = precision
+        sds = [weights.to_numpy_state_dict(sd) for sd in state_dicts]
+        self.kernel_sizes = [weights.kernel_size_of(sd) for sd in sds]
+        self.E = len(sds)
+        ks = (C.c_int * self.E)(*self.kernel_sizes)
+        h = C.c_void_p()
+        _lib.check(self.lib.camal_create(self.dev_index, self.E, ks, self.precision, C.byref(h)))
+        self._h = h
+        for e, sd in enumerate(sds):
+            blob = folded_blob(sd)
+            assert blob.size == self.lib.camal_member_blob_floats(self.kernel_sizes[e])
+            _lib.check(self.lib.camal_set_member_weights(
+                self._h, e, blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size))
+        if chunk_windows:
+            self.set_chunk_windows(chunk_windows)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.camal_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_chunk_windows(self, n):
+        _lib.check(self.lib.camal_set_chunk_windows(self._h, int(n)))
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _as_x(self, x):
+        x = torch.as_tensor(x)
+        if x.dim() == 1:
+            x = x[None, :]
+        if x.dim() == 3 and x.shape[1] == 1:
+            x = x[:, 0, :]
+        if x.dim() != 2:
+            raise ValueError(f"expected [B,L] or [B,1,L] windows, got shape {tuple(x.shape)}")
+        return x.to(device=self.device, dtype=torch.float32).contiguous()
+
+    # --- CamALResNet.forward + CAM.run for a batch (camal_forward_cam) -------------------
+    def forward_cam(self, x, member=-1, want_cam=True, cam_label=1):
+        """-> (logits [E,B,2] float32, cam [E,B,L] float32 or None) as device tensors."""
+        x = self._as_x(x)
+        B, L = x.shape
+        eo = self.E if member < 0 else 1
+        with torch.cuda.device(self.device):
+            logits = torch.empty((eo, B, 2), dtype=torch.float32, device=self.device)
+            cam = torch.empty((eo, B, L), dtype=torch.float32, device=self.device) if want_cam else None
+            _lib.check(self.lib.camal_forward_cam(self._h, _lib.ptr(x), B, L, member, cam_label,
+                                                  _lib.ptr(logits), _lib.ptr(cam), self._stream()))
+        return logits, cam
+
+    # --- CamAL.predict body + power step (camal_localize) ---------------------------------
+    def localize(self, x, x64=None, y=None, w_ma=5, gate_mode=0, pred_f64=False, p_on=None,
+                 scale_mul=1.0, scale_add=0.0, want_avg_cam=False, want_members=False, out=None):
+        """Returns a dict of device tensors: prob [B] f64, state [B,L] f32, and optionally
+        power / avg_cam / member_logits / member_cam."""
+        x = self._as_x(x)
+        B, L = x.shape
+        dev = self.device
+        with torch.cuda.device(dev):
+            if x64 is not None:
+                x64 = torch.as_tensor(x64).reshape(B, L).to(device=dev, dtype=torch.float64).contiguous()
+            if y is not None:
+                y = torch.as_tensor(np.asarray(y).astype(np.int8) if not torch.is_tensor(y) else y)
+                y = y.to(device=dev, dtype=torch.int8).contiguous()
+                if y.numel() != B:
+                    raise ValueError("y must hold one label per window")
+            o = out if out is not None else {}
+            prob = o.get("prob") if "prob" in o else torch.empty((B,), dtype=torch.float64, device=dev)
+            state = o.get("state") if "state" in o else torch.empty((B, L), dtype=torch.float32, device=dev)
+            power = None
+            if p_on is not None:
+                power = o.get("power") if "power" in o else torch.empty((B, L), dtype=torch.float32, device=dev)
+            avg = torch.empty((B, L), dtype=torch.float32, device=dev) if want_avg_cam else None
+            mlog = torch.empty((self.E, B, 2), dtype=torch.float32, device=dev) if want_members else None
+            mcam = torch.empty((self.E, B, L), dtype=torch.float32, device=dev) if want_members else None
+            _lib.check(self.lib.camal_localize(
+                self._h, _lib.ptr(x), _lib.ptr(x64), _lib.ptr(y), B, L, int(w_ma), int(gate_mode), int(bool(pred_f64)),
+                float(p_on if p_on is not None else 0.0), float(scale_mul), float(scale_add),
+                _lib.ptr(prob), _lib.ptr(avg), _lib.ptr(state), _lib.ptr(power), _lib.ptr(mlog), _lib.ptr(mcam),
+                self._stream()))
+        res = {"prob": prob, "state": state}
+        if power is not None:
+            res["power"] = power
+        if avg is not None:
+            res["avg_cam"] = avg
+        if want_members:
+            res["member_logits"], res["member_cam"] = mlog, mcam
+        return res
+
+    # --- profiling ---------------------------------------------------------------------------
+    def set_profiling(self, enabled=True):
+        _lib.check(self.lib.camal_set_profiling(self._h, int(bool(enabled))))
+
+    def get_profile(self):
+        """{class: (launches, total_ms)} since profiling was enabled (synchronises the events)."""
+        n = (C.c_int * len(_lib.PROF_CLASSES))()
+        ms = (C.c_double * len(_lib.PROF_CLASSES))()
+        _lib.check(self.lib.camal_get_profile(self._h, n, ms))
+        return {name: (int(n[i]), float(ms[i])) for i, name in enumerate(_lib.PROF_CLASSES)}

@@ -1,0 +1,128 @@
+/*
+ * camal_hip.h — C ABI of libcamal_hip.so: CamAL's detection + CAM-localization hot path
+ * (and the training step of the same ResNets) as hand-written HIP kernels for gfx950.
+ *
+ * The reference (adrienpetralia/CamAL) has no FFI of its own: its boundary is the Python
+ * surface of `CamAL` / `CamALResNet` / `CAM`.  Each entry point below names
+ * the reference code (file:line under the reference root) whose arithmetic it replaces; the
+ * Python mirror in camal_amd/ keeps the reference's names, arguments and errors and calls
+ * these through ctypes (see INTEGRATION.md for the binding).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative CAMAL_ERR_* code; the message is in
+ *     camal_last_error() (thread-local, valid until the next failing call on that thread);
+ *   - `*_dev` pointers are DEVICE pointers BORROWED from the caller (e.g. torch tensors'
+ *     data_ptr()); the library never frees them.  The context owns only its packed weights
+ *     and its activation workspace;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); all work is enqueued
+ *     on it and nothing synchronises, except camal_create / set_member_weights / destroy;
+ *   - one context per (device, stream of use); no internal locking; no exceptions cross
+ *     the ABI.
+ */
+#ifndef CAMAL_HIP_H
+#define CAMAL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAMAL_OK 0
+#define CAMAL_ERR_ARG (-1)     /* bad argument (EINVAL-like) */
+#define CAMAL_ERR_HIP (-2)     /* a HIP runtime call failed */
+#define CAMAL_ERR_STATE (-3)   /* e.g. member weights not loaded */
+#define CAMAL_ERR_NOMEM (-4)
+
+#define CAMAL_FP32 0 /* fp32 activations, v_mfma_f32_32x32x2_f32 (exact fp32)            */
+#define CAMAL_BF16 1 /* bf16 activations/weights, v_mfma_f32_32x32x16_bf16, fp32 accumulate */
+
+typedef struct camal_ctx camal_ctx;
+
+/* Version / build info of the library ("camal_hip <n> gfx950"). */
+const char* camal_version(void);
+const char* camal_last_error(void);
+
+/* Number of floats in the folded-weight blob of one member with first-kernel size k.
+ * Blob layout (all float32, BatchNorm already folded into conv weight/bias):
+ *   for each of the 9 ConvBlocks in model order (camal_resnet.py:13-18,35-38):
+ *       w'[Cout][Cin][k_i], b'[Cout]           (k_i = k,7,3 per block; camal_resnet.py:31)
+ *   residual of block 1: wr'[64][1],  br'[64]  (camal_resnet.py:51-54)
+ *   residual of block 2: wr'[128][64], br'[128]
+ *   head: W_fc[2][128], b_fc[2]                (camal_resnet.py:19)                      */
+size_t camal_member_blob_floats(int kernel_size);
+
+/* Replaces CamAL.eval()'s model materialisation (core.py:366-413): one context holds the
+ * E ensemble members (kernel_sizes[E], each odd, 1..63) on `device_id`.                   */
+int camal_create(int device_id, int n_members, const int* kernel_sizes, int precision, camal_ctx** out);
+int camal_destroy(camal_ctx* ctx);
+
+/* Upload one member's folded weights (HOST pointer, layout above); the library re-lays them
+ * out into MFMA fragment order.  Replaces load_state_dict + .to(device) (core.py:391-398). */
+int camal_set_member_weights(camal_ctx* ctx, int member, const float* folded_host, size_t n_floats);
+
+/* Windows processed per internal pass (activation workspace is sized for this many windows;
+ * default 256).                                                                           */
+int camal_set_chunk_windows(camal_ctx* ctx, int windows);
+
+/* ResNet forward + CAM for every member.  Replaces CamALResNet.forward
+ * (camal_resnet.py:21-23) and CAM.run's device part (class_activation_map.py:51-74:
+ * forward, SaveFeatures hook, W_fc[label]·F with label=1) for a batch of windows.
+ *   x_dev      [B][L] float32 (the model input, i.e. the scaled aggregate)
+ *   logits_dev [E][B][2] float32 out
+ *   cam_dev    [E][B][L] float32 out, or NULL.  cam[t] = sum_c W_fc[cam_label][c] * F[c][t]
+ *   member     -1 = all members, else only that member (outputs then have E = 1)
+ *   cam_label  0 or 1: `returned_cam_for_label` of CAM.run (class_activation_map.py:34,72)  */
+int camal_forward_cam(camal_ctx* ctx, const float* x_dev, int B, int L, int member, int cam_label,
+                      float* logits_dev, float* cam_dev, void* stream);
+
+/* Fused detection + localization + power.  Replaces the body of CamAL.predict
+ * (core.py:286-327: member loop, softmax, clip/normalise/average, vote gate,
+ * attention_sigmoid_module :415-437) and CamAL.test's power step (core.py:216-218).
+ *   x_dev       [B][L] float32 model input
+ *   x64_dev     [B][L] float64 copy of the caller's data used for the attention product
+ *               (core.py:434 multiplies by the un-cast `data`), or NULL (then x_dev is used)
+ *   y_dev       [B] int8 optional per-window gate (`y` of predict, core.py:297-300), or NULL
+ *   w_ma        moving-average window (core.py:257), >= 1
+ *   gate_mode   0: reference device=="cpu" path (no pre-filter)
+ *               1: reference device!="cpu" path: member 0's label gates every member
+ *                  (core.py:292-300).  Ignored when y_dev != NULL.
+ *   pred_f64    0: ensemble CAM accumulates in float32 (caller's data was float32)
+ *               1: in float64 (caller's data was float64) — core.py:286 zeros_like(data)
+ *   p_on        appliance mean on-power (core.py:216); used only if power_out != NULL
+ *   scale_mul, scale_add   inverse scaling agg = x*scale_mul + scale_add
+ *               (torch_dataset.py:131-156)
+ *   prob_out    [B] float64 out: ensemble detection probability (core.py:320)
+ *   avg_cam_out [B][L] float32 out or NULL: vote-gated average CAM before attention (:324)
+ *   state_out   [B][L] float32 out: on/off states (values -1,-0,0,1 like np.round, :437)
+ *   power_out   [B][L] float32 out or NULL: min(state*p_on, agg)  (core.py:216-218)
+ *   member_logits_out [E][B][2] / member_cam_out [E][B][L]: optional per-member outputs    */
+int camal_localize(camal_ctx* ctx, const float* x_dev, const double* x64_dev, const int8_t* y_dev,
+                   int B, int L, int w_ma, int gate_mode, int pred_f64,
+                   double p_on, double scale_mul, double scale_add,
+                   double* prob_out, float* avg_cam_out, float* state_out, float* power_out,
+                   float* member_logits_out, float* member_cam_out, void* stream);
+
+/* Post-processing only, on CAM rows / logits the caller already holds on the device
+ * (same arithmetic as the tail of camal_localize).  cam_dev [E][B][L], logits_dev [E][B][2]. */
+int camal_postprocess(int n_members, const float* cam_dev, const float* logits_dev,
+                      const float* x_dev, const double* x64_dev, const int8_t* y_dev,
+                      int B, int L, int w_ma, int gate_mode, int pred_f64,
+                      double p_on, double scale_mul, double scale_add,
+                      double* prob_out, float* avg_cam_out, float* state_out, float* power_out,
+                      void* stream);
+
+/* HIP-event timing of the kernels the last camal_forward_cam / camal_localize call enqueued
+ * (enable with camal_set_profiling(ctx, 1); costs two events per launch).  After the stream
+ * has been synchronised, camal_get_profile returns, per kernel class, the number of launches
+ * and the summed duration in milliseconds.  Classes: 0 stem, 1 conv (MFMA implicit GEMM),
+ * 2 conv+CAM head, 3 post-processing, 4 other.                                             */
+#define CAMAL_PROF_CLASSES 5
+int camal_set_profiling(camal_ctx* ctx, int enabled);
+int camal_get_profile(camal_ctx* ctx, int* launches /*[5]*/, double* ms /*[5]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAMAL_HIP_H */

@@ -1,0 +1,137 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden fixtures produced by
+the reference itself and against the CPU oracle on seeded inputs.
+
+Tolerances (north_star): fp32 path — detection probabilities and CAMs within 1e-3 relative
+(CAM error normalised by the row's max |CAM|), on/off states identical on >= 99.9 % of
+timestamps.  bf16 path — states identical on >= 99.9 % outside windows whose ensemble vote
+sits within bf16 noise of the 0.5 threshold; probabilities within 2e-2 absolute.
+"""
+import numpy as np
+import pytest
+
+from tests.helpers import REL_TOL_FP32, STATE_AGREE_MIN, case_state_dicts, golden_cases, load_case, rel_err
+
+pytestmark = pytest.mark.gpu
+
+CASES = golden_cases("ensemble_") + golden_cases("pair_")
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def _softmax(lg):
+    z = lg - lg.max(-1, keepdims=True)
+    e = np.exp(z)
+    return e / e.sum(-1, keepdims=True)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_fp32_members_vs_reference(torch_cuda, name):
+    from camal_amd.engine import Ensemble
+    c = load_case(name)
+    ens = Ensemble(case_state_dicts(c), device="cuda:0", precision="fp32")
+    logits, cam = ens.forward_cam(c["data"].astype(np.float32))
+    logits, cam = logits.cpu().numpy(), cam.cpu().numpy()
+    for e in range(ens.E):
+        assert rel_err(cam[e], c["cams"][e]) < REL_TOL_FP32
+        assert rel_err(logits[e].T, c["logits"][e].T) < REL_TOL_FP32
+        assert np.abs(_softmax(logits[e]) - c["probs"][e]).max() < REL_TOL_FP32
+    ens.close()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_fp32_localize_vs_reference(torch_cuda, name):
+    from camal_amd.engine import Ensemble
+    c = load_case(name)
+    data = c["data"]
+    ens = Ensemble(case_state_dicts(c), device="cuda:0", precision="fp32")
+    res = ens.localize(data.astype(np.float32), x64=data if data.dtype == np.float64 else None,
+                       w_ma=int(c["w_ma"]), gate_mode=int(bool(c["gated"])), pred_f64=data.dtype == np.float64,
+                       want_avg_cam=True)
+    prob = res["prob"].cpu().numpy()
+    state = res["state"].cpu().numpy()
+    avg = res["avg_cam"].cpu().numpy()
+    assert np.abs(prob - c["prob_detect"][:, 0]).max() < REL_TOL_FP32
+    # windows whose ensemble probability sits on the 0.5 vote threshold may legitimately flip
+    safe = np.abs(c["prob_detect"][:, 0] - 0.5) > 2e-3
+    assert safe.sum() >= len(safe) // 2
+    assert np.abs(avg[safe] - c["avg_cam"][safe]).max() < REL_TOL_FP32
+    assert (state[safe] == c["states"][safe]).mean() >= STATE_AGREE_MIN
+    # sign of zero follows np.round as well (-0.0 for small negative arguments)
+    assert (np.signbit(state[safe]) == np.signbit(c["states"][safe])).mean() >= STATE_AGREE_MIN
+    ens.close()
+
+
+@pytest.mark.parametrize("L", [1, 2, 7, 31, 129, 1000])
+def test_fp32_vs_oracle_ragged_lengths(torch_cuda, L):
+    """Edge lengths: L < k (every tap clamps), L not a multiple of the 128/256-step tiles."""
+    from camal_amd import synth, weights
+    from camal_amd.engine import Ensemble
+    from oracle import camal_oracle as oracle
+    sds = [weights.make_state_dict(k, seed=5, head_gain=3.0) for k in (5, 25)]
+    x = synth.ukdale_windows(3, max(L, 8), seed=L)[:, :L]
+    ens = Ensemble(sds, device="cuda:0", precision="fp32")
+    logits, cam = ens.forward_cam(x)
+    for e, sd in enumerate(sds):
+        cams, _labels, probs = oracle.cam_batch(sd, x, 1)
+        assert rel_err(cam[e].cpu().numpy(), cams) < REL_TOL_FP32
+        assert np.abs(_softmax(logits[e].cpu().numpy()) - probs).max() < REL_TOL_FP32
+    ens.close()
+
+
+def test_chunking_is_invisible(torch_cuda):
+    """B larger than the internal chunk gives the same numbers as one pass."""
+    from camal_amd import synth, weights
+    from camal_amd.engine import Ensemble
+    sds = [weights.make_state_dict(k, seed=9, head_gain=3.0) for k in (7, 9)]
+    x = synth.ukdale_windows(11, 200, seed=3)
+    a = Ensemble(sds, device="cuda:0", precision="fp32")
+    b = Ensemble(sds, device="cuda:0", precision="fp32", chunk_windows=4)
+    ra = a.localize(x, p_on=2000.0, scale_mul=1000.0)
+    rb = b.localize(x, p_on=2000.0, scale_mul=1000.0)
+    for k in ("prob", "state", "power"):
+        assert torch_cuda.equal(ra[k], rb[k])
+    la, ca = a.forward_cam(x)
+    lb, cb = b.forward_cam(x)
+    assert torch_cuda.equal(la, lb) and torch_cuda.equal(ca, cb)
+
+
+def test_power_and_cam_label0(torch_cuda):
+    from camal_amd import synth, weights
+    from camal_amd.engine import Ensemble
+    from oracle import camal_oracle as oracle
+    sds = [weights.make_state_dict(7, seed=2, head_gain=3.0)]
+    x = synth.ukdale_windows(4, 300, seed=8)
+    ens = Ensemble(sds, device="cuda:0", precision="fp32")
+    res = ens.localize(x, p_on=2000.0, scale_mul=1000.0)
+    state = res["state"].cpu().numpy()
+    ref = oracle.power_estimate(state, x, 2000.0, scale_mul=1000.0)
+    assert np.allclose(res["power"].cpu().numpy(), ref, rtol=1e-6, atol=1e-3)
+    _, cam0 = ens.forward_cam(x, cam_label=0)
+    ref0, _, _ = oracle.cam_batch(sds[0], x, 0)
+    assert rel_err(cam0[0].cpu().numpy(), ref0) < REL_TOL_FP32
+
+
+@pytest.mark.parametrize("name", ["ensemble_l256", "ensemble_l333_f64"])
+def test_bf16_localize_vs_reference(torch_cuda, name):
+    from camal_amd.engine import Ensemble
+    c = load_case(name)
+    data = c["data"]
+    ens = Ensemble(case_state_dicts(c), device="cuda:0", precision="bf16")
+    res = ens.localize(data.astype(np.float32), x64=data if data.dtype == np.float64 else None,
+                       w_ma=int(c["w_ma"]), pred_f64=data.dtype == np.float64, want_members=True)
+    prob = res["prob"].cpu().numpy()
+    state = res["state"].cpu().numpy()
+    assert np.abs(prob - c["prob_detect"][:, 0]).max() < 2e-2
+    # members whose own vote is not within bf16 noise of 0.5 must agree on the label
+    probs_m = _softmax(res["member_logits"].cpu().numpy())
+    firm = np.abs(c["probs"][..., 1] - 0.5) > 5e-2
+    assert ((probs_m[..., 1] > 0.5) == (c["labels"] > 0))[firm].all()
+    safe = (np.abs(c["prob_detect"][:, 0] - 0.5) > 5e-2) & firm.all(axis=0)
+    assert safe.sum() >= len(safe) // 2
+    assert (state[safe] == c["states"][safe]).mean() >= STATE_AGREE_MIN
+    ens.close()
