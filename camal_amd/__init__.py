@@ -1,0 +1,26 @@
+"""camal_amd — MI355X-native implementation of CamAL's detection + CAM-localization hot path.
+
+Public surface mirrors the reference (adrienpetralia/CamAL):
+    from camal_amd import CamAL, CamALResNet, CAM
+Everything heavy is imported lazily so that ``import camal_amd`` works without a GPU.
+"""
+__all__ = ["CamAL", "CamALResNet", "CAM", "Ensemble", "NILMmetrics", "Classifmetrics"]
+
+
+def __getattr__(name):
+    if name == "CamAL":
+        from .core import CamAL
+        return CamAL
+    if name == "CamALResNet":
+        from .resnet import CamALResNet
+        return CamALResNet
+    if name == "CAM":
+        from .cam import CAM
+        return CAM
+    if name == "Ensemble":
+        from .engine import Ensemble
+        return Ensemble
+    if name in ("NILMmetrics", "Classifmetrics"):
+        from . import metrics
+        return getattr(metrics, name)
+    raise AttributeError(name)

@@ -35,6 +35,7 @@ SIGNATURES = {
     "camal_forward_cam": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "camal_localize": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "camal_postprocess": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _vp, _vp, _vp, _vp, _vp]),
+    "camal_attention": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "camal_set_profiling": (_i, [_vp, _i]),
     "camal_get_profile": (_i, [_vp, C.POINTER(_i), C.POINTER(_d)]),
 }

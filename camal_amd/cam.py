@@ -1,0 +1,47 @@
+"""``CAM`` — mirror of ``src/helpers/class_activation_map.py:24-74``.
+
+``CAM(model, device, last_conv_layer, fc_layer_name).run(instance, returned_cam_for_label=1)``
+returns ``(cam[L] float32, label_pred int, proba[2] float32)`` exactly like the reference,
+but the forward, the "hook" on the last block and the ``W_fc[label]·F`` product all happen
+inside one ``camal_forward_cam`` call: the 128 x L feature map never leaves the GPU (it is
+never even written to HBM).  ``run_batch`` is the batched form ``CamAL.predict`` needs.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+class CAM:
+    def __init__(self, model, device, last_conv_layer="layer3", fc_layer_name="fc1", verbose=False):
+        self.device = device
+        self.last_conv_layer = last_conv_layer
+        self.fc_layer_name = fc_layer_name
+        self.model = model
+        self.verbose = verbose
+        idx = getattr(last_conv_layer, "index", 2)
+        if idx != 2:
+            raise NotImplementedError("the fused CAM head taps the last ResNetBlock (reference core.py:403)")
+
+    def run(self, instance, label_instance=None, returned_cam_for_label=None):
+        assert label_instance is not None or returned_cam_for_label is not None
+        cams, labels, probs = self.run_batch(np.array(instance)[None, :], returned_cam_for_label)
+        if self.verbose:
+            print("Pred proba :", probs[0])
+        return cams[0], int(labels[0]), probs[0]
+
+    def run_batch(self, data, returned_cam_for_label=1):
+        """data [N,L] -> (cams [N,L] f32, labels [N] int, probs [N,2] f32) as NumPy arrays."""
+        eng = self.model.engine()
+        x = np.asarray(data)
+        want = 1 if returned_cam_for_label is None else int(returned_cam_for_label)
+        logits, cam = eng.forward_cam(x, cam_label=want)
+        probs = torch.softmax(logits[0], dim=1)
+        labels = torch.topk(probs, 1)[1][:, 0].int()
+        if returned_cam_for_label is None:
+            # class_activation_map.py:69-70: CAM of the predicted class; redo the rows that predicted 0
+            zero = (labels == 0).nonzero()[:, 0]
+            if len(zero):
+                _, cam0 = eng.forward_cam(torch.as_tensor(x)[zero.cpu()], cam_label=0)
+                cam[0][zero] = cam0[0]
+        return cam[0].cpu().numpy(), labels.cpu().numpy(), probs.cpu().numpy()

@@ -1,0 +1,304 @@
+"""``CamAL`` — drop-in mirror of the reference's public class (``src/models/camal/core.py:19``).
+
+Same constructor, ``train / predict / __call__ / test / load / eval / to`` signatures, same
+``camal_logs`` dictionary schema and the same exceptions; everything from "ResNet forward"
+downward (and the per-window Python loops of ``predict``) runs in libcamal_hip.so on MI355X.
+
+Deliberate normalisations of reference quirks:
+  * ``device`` must be a GPU ("cuda", "cuda:N"); the default ``"cpu"`` of the reference has no
+    meaning here and raises.  ``predict`` follows the reference's *CPU-path* semantics (no
+    member-0 pre-filter) unless ``self.prefilter = True`` (its ``device != 'cpu'`` path).
+  * ``test`` returns ``(localization_metrics, classification_metrics)``: the reference builds
+    a set literal of dicts (core.py:235-240), which raises ``TypeError``; its own scripts
+    unpack two values (scripts/ukdale.py:144).
+  * ``test`` without a scaler treats the data as unscaled (the reference hits a ``NameError``
+    after printing its warning, core.py:205-212).
+"""
+from __future__ import annotations
+
+import heapq
+import pickle
+import time
+import warnings
+
+import numpy as np
+import torch
+
+from .cam import CAM
+from .engine import Ensemble
+from .metrics import Classifmetrics, NILMmetrics
+from .resnet import CamALResNet
+
+
+def nilmdataset_to_clfdataset(data):
+    """Weak window labels of a 4-D NILM array (reference data_processing.py:17-33)."""
+    labels = [1 if data[i, 1, 1, :].any() > 0 else 0 for i in range(len(data))]
+    return data[:, 0, 0, :], np.array(labels)
+
+
+def undersampler(X, y, sampling_strategy="auto", seed=0):
+    """Random under-sampling to the minority-class count, then a seeded shuffle
+    (reference data_processing.py:37-57).  imblearn is not available here: this restates
+    ``RandomUnderSampler(sampling_strategy='auto', random_state=seed)`` (per class, in sorted
+    class order, ``RandomState(seed).choice(n_class, n_min, replace=False)``); exact index
+    parity with imblearn is unpinned."""
+    if sampling_strategy != "auto":
+        raise NotImplementedError("only sampling_strategy='auto'")
+    X = np.asarray(X)
+    y = np.asarray(y).astype(int).ravel()
+    classes, counts = np.unique(y, return_counts=True)
+    n_min = counts.min()
+    rs = np.random.RandomState(seed)
+    idx = []
+    for c, n in zip(classes, counts):
+        members = np.flatnonzero(y == c)
+        idx.append(members if n == n_min else members[rs.choice(range(n), size=n_min, replace=False)])
+    idx = np.concatenate(idx)
+    mat = np.concatenate((X[idx], y[idx].reshape(-1, 1)), axis=1)
+    np.random.seed(seed)
+    np.random.shuffle(mat)
+    mat = mat.astype(np.float32)
+    return mat[:, :-1], mat[:, -1]
+
+
+def _scaler_affine(scaler):
+    """(mul, add) of NILMscaler.inverse_transform for the aggregate channel
+    (reference torch_dataset.py:141-144)."""
+    if scaler is None:
+        return 1.0, 0.0
+    s1, s2 = float(scaler.power_stat1), float(scaler.power_stat2)
+    if getattr(scaler, "power_scaling_type", None) == "MinMax":
+        return s2 - s1, s1
+    return s2, s1
+
+
+class CamAL(object):
+    def __init__(self, n_predictors=5, device="cuda", batch_inference=128,
+                 loc_metrics=NILMmetrics(), clf_metrics=Classifmetrics(), **resnet_kwargs):
+        self.device = device
+        self.n_predictors = n_predictors
+        self.batch_inference = batch_inference
+        self.loc_metrics = loc_metrics
+        self.clf_metrics = clf_metrics
+
+        resnet_kwargs.setdefault("in_channels", 1)
+        resnet_kwargs.setdefault("mid_channels", 64)
+        resnet_kwargs.setdefault("norm", "BatchNorm")
+        self.resnet_kwargs = resnet_kwargs
+
+        self.is_fitted = False
+        self.camal_logs = None
+        self.list_resnet_predictors = None
+        self.list_cam_predictors = None
+
+        # knobs that do not exist in the reference
+        self.precision = "fp32"   # "bf16": bf16 MFMA convs with fp32 accumulation
+        self.prefilter = False    # True: reference device!='cpu' gating (core.py:292-300)
+        self._ensemble = None
+
+    # ------------------------------------------------------------------ train (core.py:47-189)
+    def train(self, train_dataset: tuple, valid_dataset: tuple, test_dataset: tuple,
+              list_kernel_sizes: list = [5, 7, 9, 15, 25], n_try_by_kernel: int = 1,
+              path: str = None, **training_kwargs):
+        assert n_try_by_kernel * len(list_kernel_sizes) >= self.n_predictors, (
+            "The number of keep predictors does not meet the number of kernel to try and the try by kernel.")
+        from .trainer import BasedClassifTrainer, TSLoader
+
+        training_kwargs.setdefault("batch_size", 128)
+        training_kwargs.setdefault("epochs", 50)
+        training_kwargs.setdefault("lr", 1e-3)
+        training_kwargs.setdefault("weight_decay", 0)
+        training_kwargs.setdefault("patience_es", 5)
+        training_kwargs.setdefault("patience_rlr", 3)
+        training_kwargs.setdefault("n_warmup_epochs", 1)
+        training_kwargs.setdefault("all_gpu", False)
+
+        X_train, y_train = train_dataset[0], train_dataset[1]
+        X_valid, y_valid = valid_dataset[0], valid_dataset[1]
+        X_test, y_test = test_dataset[0], test_dataset[1]
+        X_train, y_train = undersampler(X_train, y_train, sampling_strategy="auto", seed=0)
+
+        tmp_loss_results = {}
+        camal_logs = {"ensemble_training_logs": {}}
+        start_training_time = time.time()
+
+        idx_clf = 0
+        for kernel_size in list_kernel_sizes:
+            for nth_try in range(n_try_by_kernel):
+                resnet_inst = CamALResNet(kernel_size=kernel_size, **self.resnet_kwargs)
+                train_loader = TSLoader(X_train, y_train, batch_size=training_kwargs["batch_size"], shuffle=True)
+                valid_loader = TSLoader(X_valid, y_valid, batch_size=1, shuffle=False)
+                test_loader = TSLoader(X_test, y_test, batch_size=1, shuffle=False)
+                clf_trainer = BasedClassifTrainer(
+                    resnet_inst, train_loader=train_loader, valid_loader=valid_loader,
+                    learning_rate=training_kwargs["lr"], weight_decay=training_kwargs["weight_decay"],
+                    patience_es=training_kwargs["patience_es"], patience_rlr=training_kwargs["patience_rlr"],
+                    n_warmup_epochs=training_kwargs["n_warmup_epochs"], device=self.device,
+                    all_gpu=training_kwargs["all_gpu"])
+                clf_trainer.train(training_kwargs["epochs"])
+                clf_trainer.restore_best_weights()
+                loss_eval, _ = clf_trainer.evaluate(test_loader)
+                print(f"Trained predictor {idx_clf} with kernel size: {kernel_size} (nth_try {nth_try}) - loss: {loss_eval}.")
+
+                tmp_loss_results[f"Predictor_{idx_clf}"] = loss_eval
+                camal_logs["ensemble_training_logs"][f"Predictor_{idx_clf}"] = clf_trainer.log
+                camal_logs["ensemble_training_logs"][f"Predictor_{idx_clf}"]["kernel_size"] = kernel_size
+                camal_logs["ensemble_training_logs"][f"Predictor_{idx_clf}"]["nth_try"] = nth_try
+                idx_clf += 1
+
+        camal_logs["training_time"] = round((time.time() - start_training_time), 3)
+
+        heap = [(loss, name) for name, loss in tmp_loss_results.items()]
+        heapq.heapify(heap)
+        smallest = heapq.nsmallest(self.n_predictors, heap)
+        list_best_clf = [name for _, name in smallest]
+        camal_logs["camal_predictors_id"] = list_best_clf
+        for i in range(idx_clf):
+            if f"Predictor_{i}" not in list_best_clf:
+                camal_logs["ensemble_training_logs"][f"Predictor_{i}"].pop("best_model_state_dict", None)
+        camal_logs["is_fitted"] = True
+
+        if path is not None:
+            with open(path, "wb") as f:
+                pickle.dump(camal_logs, f, protocol=pickle.HIGHEST_PROTOCOL)
+
+        self.camal_logs = camal_logs
+        self.is_fitted = True
+        self.eval()
+        return
+
+    # ------------------------------------------------------------------ test (core.py:191-240)
+    def test(self, data_test, appliance_mean_on_power=None, scaler=None):
+        if len(data_test.shape) < 4:
+            raise ValueError("Provided test data need to be given in NILM standard (4D numpy array)")
+
+        data = data_test[:, 0, 0, :]
+        if appliance_mean_on_power is not None:
+            if scaler is None:
+                warnings.warn("No scaler provided for inverse_transform, are you sure you didn't scale the data for training?")
+            mul, add = _scaler_affine(scaler)
+            soft_label, prob_detect, y_hat = self._predict_impl(
+                data, return_prob=True, p_on=float(appliance_mean_on_power), scale_mul=mul, scale_add=add)
+        else:
+            soft_label, prob_detect = self._predict_impl(data, return_prob=True)
+
+        y_state = data_test[:, 1, 1, :].ravel().astype(dtype=int)
+        y_hat_state = soft_label.ravel().astype(dtype=int)
+
+        if appliance_mean_on_power is not None:
+            rescaled = scaler.inverse_transform(data_test) if scaler is not None else data_test
+            y = rescaled[:, 1, 0, :].ravel()
+            metric_softlabel = self.loc_metrics(y, y_hat.ravel(), y_state, y_hat_state)
+        else:
+            metric_softlabel = self.loc_metrics(y=None, y_hat=None, y_state=y_state, y_hat_state=y_hat_state)
+
+        _, y_clf_true = nilmdataset_to_clfdataset(data_test)
+        metric_classif = self.clf_metrics(y=y_clf_true.ravel(), y_hat=prob_detect.ravel())
+        return metric_softlabel, metric_classif
+
+    # ------------------------------------------------------------------ load (core.py:242-250)
+    def load(self, path: str):
+        with open(path, "rb") as handle:
+            self.camal_logs = pickle.load(handle)
+        print("Log successfully loaded.")
+        self.is_fitted = self.camal_logs["is_fitted"]
+        self.list_resnet_predictors = None
+        return
+
+    # --------------------------------------------------------------- predict (core.py:252-332)
+    def predict(self, data: np.array, y: np.array = None, return_prob: bool = False, w_ma: int = 5):
+        """Per-timestamp on/off localization of the appliance for windows ``data`` [N,L] or [L].
+        Returns states [N,L] float64 in {-1,-0,0,1} (and ``prob_detect`` [N,1] float64)."""
+        return self._predict_impl(data, y=y, return_prob=return_prob, w_ma=w_ma)
+
+    def _predict_impl(self, data, y=None, return_prob=False, w_ma=5, p_on=None, scale_mul=1.0, scale_add=0.0):
+        if not self.is_fitted:
+            raise ValueError(
+                "CamAL instance is not fitted. Train CamAL or load a fitted instance of CamAL before trying to predict.")
+        data = np.asarray(data)
+        assert len(data.shape) <= 2, (
+            f"Input data need to be a 1D or 2D (batched) numpy array, got a {len(data.shape)}D array of size {data.shape}.")
+        if len(data.shape) == 1:
+            data = np.expand_dims(data, axis=0)
+        if self.list_resnet_predictors is None:
+            self.eval()
+
+        is64 = data.dtype != np.float32
+        res = self._ensemble.localize(
+            np.ascontiguousarray(data, dtype=np.float32),
+            x64=np.ascontiguousarray(data, dtype=np.float64) if is64 else None,
+            y=y, w_ma=w_ma, gate_mode=int(bool(self.prefilter)), pred_f64=is64,
+            p_on=p_on, scale_mul=scale_mul, scale_add=scale_add)
+        prediction = res["state"].cpu().numpy().astype(np.float64)
+        prob_detect = res["prob"].cpu().numpy().reshape(-1, 1)
+        out = [prediction]
+        if return_prob:
+            out.append(prob_detect)
+        if p_on is not None:
+            out.append(res["power"].cpu().numpy().astype(np.float64))
+        return out[0] if len(out) == 1 else tuple(out)
+
+    def __call__(self, data: np.array, y: np.array = None, return_prob: bool = False):
+        return self.predict(data, y=y, return_prob=return_prob)
+
+    # -------------------------------------------------------------------- to (core.py:346-364)
+    def to(self, device: str) -> None:
+        if self.list_resnet_predictors is not None:
+            for predictors in self.list_resnet_predictors:
+                predictors.to(device)
+            self.device = device
+            self.eval()
+        else:
+            warnings.warn("Cannot move anything to a device: no predictors in cache.")
+            self.device = device
+        return
+
+    # ------------------------------------------------------------------ eval (core.py:366-413)
+    def eval(self) -> None:
+        if not self.is_fitted:
+            raise ValueError(
+                "CamAL instance is not fitted. Train CamAL or load a fitted instance of CamAL before trying to move it in eval mode.")
+        list_resnet_predictors, list_cam_predictors, sds = [], [], []
+        for resnet_name in self.camal_logs["camal_predictors_id"]:
+            log = self.camal_logs["ensemble_training_logs"][resnet_name]
+            resnet_inst = CamALResNet(kernel_size=log["kernel_size"])  # defaults, like core.py:386-390
+            resnet_inst.to(self.device)
+            resnet_inst.load_state_dict(log["best_model_state_dict"])
+            resnet_inst.eval()
+            cam_resnet_inst = CAM(model=resnet_inst, device=self.device,
+                                  last_conv_layer=resnet_inst._modules["layers"][2],
+                                  fc_layer_name=resnet_inst._modules["linear"])
+            list_resnet_predictors.append(resnet_inst)
+            list_cam_predictors.append(cam_resnet_inst)
+            sds.append(resnet_inst._params)
+        self.list_resnet_predictors = list_resnet_predictors
+        self.list_cam_predictors = list_cam_predictors
+        if self._ensemble is not None:
+            self._ensemble.close()
+        self._ensemble = Ensemble(sds, device=self.device, precision=self.precision)
+        return
+
+    # -------------------------------------------- helpers kept for API parity (core.py:415-482)
+    def attention_sigmoid_module(self, data: np.array, soft_label: np.array, w_ma: int = 5) -> np.array:
+        """Moving average + rectified sigmoid + round of an averaged CAM (core.py:415-437), on the
+        device (``camal_attention``).  ``predict`` does not call this: its fused kernel includes it."""
+        from . import _lib
+        lib = _lib.load()
+        data = np.atleast_2d(np.asarray(data, dtype=np.float64))
+        soft = np.atleast_2d(np.asarray(soft_label, dtype=np.float64))
+        B, L = data.shape
+        dev = torch.device(self.device)
+        with torch.cuda.device(dev):
+            s_d = torch.from_numpy(np.ascontiguousarray(soft)).to(dev)
+            x_d = torch.from_numpy(np.ascontiguousarray(data)).to(dev)
+            out = torch.empty_like(x_d)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(lib.camal_attention(_lib.ptr(s_d), _lib.ptr(x_d), B, L, int(w_ma), _lib.ptr(out), stream))
+        return out.cpu().numpy()
+
+    def _predict_subsequence_class(self, model, data) -> np.array:
+        """Batched argmax of one member's logits (core.py:463-482)."""
+        model.to(self.device)
+        model.eval()
+        logits = model(np.asarray(data, dtype=np.float32))
+        return torch.max(logits, 1)[1].cpu().numpy().flatten().astype(np.int8)

@@ -428,6 +428,15 @@ int camal_localize(camal_ctx* c, const float* x, const double* x64, const int8_t
     return 0;
 }
 
+int camal_attention(const double* soft, const double* x, int B, int L, int w_ma, double* state_out, void* stream) {
+    if (!soft || !x || !state_out) return fail(CAMAL_ERR_ARG, "null argument");
+    if (B < 1 || L < 1) return fail(CAMAL_ERR_ARG, "B and L must be >= 1");
+    if (w_ma < 1) return fail(CAMAL_ERR_ARG, "w_ma must be >= 1");
+    hipLaunchKernelGGL(attention_kernel, dim3((L + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, soft, x, state_out, L, w_ma);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int camal_set_profiling(camal_ctx* c, int enabled) {
     if (!c) return fail(CAMAL_ERR_ARG, "null context");
     c->prof = enabled != 0;

@@ -440,4 +440,20 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
     }
 }
 
+// Standalone attention_sigmoid_module (core.py:415-437) on an already averaged soft label:
+// ma = convolve(soft, ones(w), 'same')/w ; s = 2/(1+exp(-ma*x))-1 ; round half to even.
+__global__ __launch_bounds__(256) void attention_kernel(const double* __restrict__ soft, const double* __restrict__ x,
+                                                        double* __restrict__ out, int L, int w) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= L) return;
+    const int hi = (w - 1) / 2, lo = hi - w + 1;
+    const double* sb = soft + (size_t)b * L;
+    double sum = 0.0;
+    for (int m = t + lo; m <= t + hi; ++m)
+        if (m >= 0 && m < L) sum += sb[m];
+    const double z = (sum / (double)w) * x[(size_t)b * L + t];
+    out[(size_t)b * L + t] = rint(2.0 * (1.0 / (1.0 + exp(-z))) - 1.0);
+}
+
 }  // namespace camal

@@ -113,6 +113,11 @@ int camal_postprocess(int n_members, const float* cam_dev, const float* logits_d
                       double* prob_out, float* avg_cam_out, float* state_out, float* power_out,
                       void* stream);
 
+/* CamAL.attention_sigmoid_module on its own (core.py:415-437): moving average (zero edges),
+ * rectified sigmoid of ma*x, round half to even.  soft_dev, x_dev, state_out: [B][L] float64. */
+int camal_attention(const double* soft_dev, const double* x_dev, int B, int L, int w_ma,
+                    double* state_out, void* stream);
+
 /* HIP-event timing of the kernels the last camal_forward_cam / camal_localize call enqueued
  * (enable with camal_set_profiling(ctx, 1); costs two events per launch).  After the stream
  * has been synchronised, camal_get_profile returns, per kernel class, the number of launches

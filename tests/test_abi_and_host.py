@@ -1,0 +1,142 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/camal_hip.h declares
+(no compute calls), and the host-side mirror of the reference API behaves like the reference
+where no GPU is needed (schema, errors, folding, metrics, sampling)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "camal_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(camal_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from camal_amd import _lib
+    lib = _lib.load()
+    syms = _declared_symbols()
+    assert len(syms) >= 12
+    for s in syms:
+        assert hasattr(lib, s), f"libcamal_hip.so lacks {s}"
+        assert s in _lib.SIGNATURES, f"ctypes binding lacks {s}"
+    assert set(_lib.SIGNATURES) == set(syms)
+    assert b"gfx950" in lib.camal_version()
+
+
+def test_blob_size_matches_parameter_count():
+    from camal_amd import _lib, weights
+    from camal_amd.engine import folded_blob
+    lib = _lib.load()
+    for k in (5, 7, 9, 15, 25):
+        sd = weights.make_state_dict(k, seed=0)
+        blob = folded_blob(sd)
+        # folding removes the 4 BN vectors per conv and keeps conv w + b: same count as w+b+head
+        assert blob.size == lib.camal_member_blob_floats(k)
+        # P(k) = M(k) + 3714 trainable parameters, M(k) = 24640 k + 376896
+        assert weights.count_parameters(k) == 24640 * k + 376896 + 3714
+
+
+def test_argument_errors_without_gpu():
+    from camal_amd import _lib
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    ks = (ctypes.c_int * 1)(8)  # even kernel size
+    assert lib.camal_create(0, 1, ks, 0, ctypes.byref(h)) == -1
+    assert b"odd" in lib.camal_last_error()
+    ks = (ctypes.c_int * 1)(7)
+    assert lib.camal_create(0, 1, ks, 7, ctypes.byref(h)) == -1  # bad precision
+    assert lib.camal_create(0, 0, ks, 0, ctypes.byref(h)) == -1  # no members
+    assert lib.camal_postprocess(1, None, None, None, None, None, 1, 1, 5, 0, 0, 0.0, 1.0, 0.0, None, None, None, None, None) == -1
+
+
+def test_state_dict_schema_is_the_reference_one():
+    from camal_amd import weights
+    spec = weights.state_dict_spec(7)
+    assert len(spec) == 79
+    assert spec["layers.1.layers.0.layers.0.weight"][0] == (128, 64, 7)
+    assert spec["layers.0.residual.0.weight"][0] == (64, 1, 1)
+    assert spec["layers.1.residual.1.running_var"][0] == (128,)
+    assert "layers.2.residual.0.weight" not in spec  # block 3 has no skip (quirk 2)
+    assert spec["linear.weight"][0] == (2, 128)
+    assert [k for _, _, _, k in weights.conv_layers(25)] == [25, 7, 3, 25, 7, 3, 25, 7, 3]
+
+
+def test_resnet_mirror_state_dict_roundtrip():
+    from camal_amd import weights
+    from camal_amd.resnet import CamALResNet
+    m = CamALResNet(kernel_size=9)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(weights.state_dict_spec(9).keys())
+    assert float(sd["layers.0.layers.0.layers.1.weight"].min()) == 1.0  # BN gamma init
+    new = weights.make_state_dict(9, seed=4)
+    m.load_state_dict(new)
+    assert np.array_equal(m.state_dict()["linear.weight"].numpy(), new["linear.weight"])
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({"linear.weight": new["linear.weight"]})
+    bad = dict(new)
+    bad["linear.weight"] = np.zeros((3, 128), np.float32)
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(bad)
+    assert len(m.parameters()) == len(weights.trainable_keys(9))
+
+
+def test_camal_errors_like_the_reference():
+    from camal_amd import CamAL
+    c = CamAL(device="cuda")
+    with pytest.raises(ValueError):  # core.py:271-274
+        c.predict(np.zeros((2, 16), np.float32))
+    with pytest.raises(ValueError):  # core.py:377-380
+        c.eval()
+    with pytest.raises(ValueError):  # core.py:192-195
+        c.test(np.zeros((2, 2, 16)))
+    c.is_fitted = True
+    with pytest.raises(AssertionError):  # core.py:276-278
+        c.predict(np.zeros((2, 2, 16), np.float32))
+    assert c.resnet_kwargs == {"in_channels": 1, "mid_channels": 64, "norm": "BatchNorm"}
+    with pytest.raises(AssertionError):  # core.py:66-68
+        CamAL(n_predictors=5).train((None, None), (None, None), (None, None), list_kernel_sizes=[5, 7])
+
+
+def test_cpu_device_is_refused_loudly():
+    from camal_amd import _lib, weights
+    from camal_amd.engine import Ensemble
+    with pytest.raises(_lib.CamalHipError):
+        Ensemble([weights.make_state_dict(7)], device="cpu")
+
+
+def test_undersampler_balances_and_is_seeded():
+    from camal_amd.core import undersampler
+    rng = np.random.default_rng(0)
+    X = rng.normal(size=(100, 8))
+    y = (rng.random(100) < 0.25).astype(int)
+    Xa, ya = undersampler(X, y, seed=0)
+    Xb, yb = undersampler(X, y, seed=0)
+    assert Xa.dtype == np.float32 and np.array_equal(Xa, Xb) and np.array_equal(ya, yb)
+    assert (ya == 1).sum() == (ya == 0).sum() == y.sum()
+
+
+def test_metrics_keys_and_values():
+    from camal_amd.metrics import Classifmetrics, NILMmetrics
+    y = np.array([0, 0, 1, 1, 1, 0])
+    p = np.array([0.1, 0.6, 0.8, 0.4, 0.9, 0.2])
+    m = Classifmetrics()(y, p)
+    assert set(m) == {"ACCURACY", "BALANCED_ACCURACY", "PRECISION", "RECALL", "F1_SCORE", "F1_SCORE_MACRO",
+                      "ROC_AUC_SCORE", "AP"}
+    assert m["ACCURACY"] == round(4 / 6, 5) and m["ROC_AUC_SCORE"] == round(8 / 9, 5)
+    n = NILMmetrics()(y=np.array([0.0, 10.0, 20.0]), y_hat=np.array([0.0, 10.0, 10.0]),
+                      y_state=np.array([0, 1, 1]), y_hat_state=np.array([0, 1, 1]))
+    assert n["MAE"] == round(10 / 3, 3) and n["F1_SCORE"] == 1.0 and n["TECA"] == round(1 - 10 / 60, 3)
+
+
+def test_nilm_to_clf_labels():
+    from camal_amd.core import nilmdataset_to_clfdataset
+    d = np.zeros((3, 2, 2, 5))
+    d[1, 1, 1, 2] = 1
+    X, y = nilmdataset_to_clfdataset(d)
+    assert X.shape == (3, 5) and list(y) == [0, 1, 0]

@@ -1,0 +1,128 @@
+"""GPU tests of the drop-in Python surface (CamAL / CamALResNet / CAM) against the fixtures
+the reference itself produced — these read like calls into the reference's own classes."""
+import pickle
+
+import numpy as np
+import pytest
+
+from tests.helpers import REL_TOL_FP32, STATE_AGREE_MIN, case_state_dicts, load_case, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _fitted_camal(case, **kw):
+    import torch
+    from camal_amd import CamAL
+    logs = {"ensemble_training_logs": {}, "camal_predictors_id": [], "is_fitted": True}
+    for e, (k, sd) in enumerate(zip(case["members"], case_state_dicts(case))):
+        name = f"Predictor_{e}"
+        logs["ensemble_training_logs"][name] = {
+            "kernel_size": int(k), "best_model_state_dict": {kk: torch.from_numpy(np.array(v)) for kk, v in sd.items()}}
+        logs["camal_predictors_id"].append(name)
+    camal = CamAL(n_predictors=len(case["members"]), device="cuda:0", **kw)
+    camal.camal_logs = logs
+    camal.is_fitted = True
+    return camal
+
+
+@pytest.mark.parametrize("name", ["ensemble_l256", "ensemble_l333_f64", "ensemble_l200_signed", "pair_l128_wma4"])
+def test_camal_predict_matches_reference(name):
+    c = load_case(name)
+    camal = _fitted_camal(c)
+    states, prob = camal.predict(c["data"], return_prob=True, w_ma=int(c["w_ma"]))
+    assert states.shape == c["states"].shape and states.dtype == np.float64
+    assert prob.shape == c["prob_detect"].shape and prob.dtype == np.float64
+    assert np.abs(prob - c["prob_detect"]).max() < REL_TOL_FP32
+    safe = np.abs(c["prob_detect"][:, 0] - 0.5) > 2e-3
+    assert (states[safe] == c["states"][safe]).mean() >= STATE_AGREE_MIN
+    only_states = camal(c["data"][0])  # 1-D input + __call__ (core.py:280-281,334-344)
+    assert only_states.shape == (1, c["data"].shape[1])
+
+
+def test_camal_prefilter_is_the_reference_device_path():
+    c = load_case("ensemble_l160_gated")
+    camal = _fitted_camal(c)
+    camal.prefilter = True
+    states, prob = camal.predict(c["data"], return_prob=True)
+    assert np.abs(prob - c["prob_detect"]).max() < REL_TOL_FP32
+    assert (prob == 0).any()  # gated windows keep prob 0 for every member (quirk 7)
+    safe = np.abs(c["prob_detect"][:, 0] - 0.5) > 2e-3
+    assert (states[safe] == c["states"][safe]).mean() >= STATE_AGREE_MIN
+    # explicit y gate (core.py:297-300)
+    y = np.array([1, 0] * (len(c["data"]) // 2), np.int8)
+    camal.prefilter = False
+    s2, p2 = camal.predict(c["data"], y=y, return_prob=True)
+    assert (p2[y == 0] == 0).all() and (s2[y == 0] == 0).all()
+
+
+def test_cam_run_matches_reference():
+    import torch
+    from camal_amd import CAM, CamALResNet
+    c = load_case("ensemble_l64_degenerate")
+    sd = case_state_dicts(c)[1]
+    m = CamALResNet(kernel_size=int(c["members"][1]))
+    m.to("cuda:0")
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    m.eval()
+    cam = CAM(model=m, device="cuda:0", last_conv_layer=m._modules["layers"][2], fc_layer_name=m._modules["linear"])
+    for i in range(len(c["data"])):
+        got, label, proba = cam.run(instance=c["data"][i], returned_cam_for_label=1)
+        assert got.dtype == np.float32 and got.shape == (c["data"].shape[1],)
+        assert rel_err(got, c["cams"][1][i]) < REL_TOL_FP32
+        assert np.abs(proba - c["probs"][1][i]).max() < REL_TOL_FP32
+        if abs(c["probs"][1][i][1] - 0.5) > 1e-3:
+            assert label == c["labels"][1][i]
+    logits = m(torch.from_numpy(c["data"][:, None, :]).float())
+    assert tuple(logits.shape) == (len(c["data"]), 2)
+    assert rel_err(logits.cpu().numpy().T, c["logits"][1].T) < REL_TOL_FP32
+
+
+def test_camal_load_and_test(tmp_path):
+    """camal_logs pickle round trip (core.py:181-183,242-250) and CamAL.test (core.py:191-240)."""
+    from oracle import camal_oracle as oracle
+    c = load_case("ensemble_l256")
+    camal = _fitted_camal(c)
+    path = tmp_path / "camal_logs.pkl"
+    with open(path, "wb") as f:
+        pickle.dump(camal.camal_logs, f)
+    from camal_amd import CamAL
+    fresh = CamAL(n_predictors=5, device="cuda:0")
+    fresh.load(str(path))
+    assert fresh.is_fitted
+
+    n, L = c["data"].shape
+
+    class Scaler:  # NILMscaler with an integer power_scaling (torch_dataset.py:63-65,144)
+        power_scaling_type = 1000
+        power_stat1, power_stat2 = 0, 1000
+
+        def inverse_transform(self, d):
+            r = d.copy()
+            r[:, 0, 0, :] = r[:, 0, 0, :] * 1000
+            return r
+
+    data4 = np.zeros((n, 2, 2, L))
+    data4[:, 0, 0, :] = c["data"]
+    data4[:, 1, 1, :] = (c["states"] > 0)           # "true" states
+    data4[:, 1, 0, :] = (c["states"] > 0) * 1800.0   # true appliance power in W
+    loc, clf = fresh.test(data4, appliance_mean_on_power=2000.0, scaler=Scaler())
+    assert loc["F1_SCORE"] > 0.99 and "MAE" in loc and "TECA" in loc
+    assert set(clf) >= {"ACCURACY", "ROC_AUC_SCORE", "AP"}
+    ref_power = oracle.power_estimate(c["states"], c["data"], 2000.0, scale_mul=1000.0)
+    y = data4[:, 1, 0, :].ravel()
+    assert abs(loc["MAE"] - round(float(np.mean(np.abs(y - ref_power.ravel()))), 3)) < 0.5
+    loc2, _ = fresh.test(data4)
+    assert "MAE" not in loc2 and "F1_SCORE" in loc2
+
+
+def test_attention_module_and_subsequence_class():
+    from oracle import camal_oracle as oracle
+    c = load_case("ensemble_l256")
+    camal = _fitted_camal(c)
+    camal.eval()
+    got = camal.attention_sigmoid_module(c["data"], c["avg_cam"], w_ma=5)
+    ref = oracle.attention_sigmoid_module(c["data"], c["avg_cam"], w_ma=5)
+    assert (got == ref).mean() >= STATE_AGREE_MIN
+    y = camal._predict_subsequence_class(camal.list_resnet_predictors[0], c["data"])
+    firm = np.abs(c["probs"][0][:, 1] - 0.5) > 1e-3
+    assert y.dtype == np.int8 and (y[firm] == c["labels"][0][firm]).all()

@@ -89,3 +89,13 @@ def test_fold_bn_equivalence():
                             sd[p + ".layers.1.bias"], sd[p + ".layers.1.running_mean"], sd[p + ".layers.1.running_var"])
     y2 = oracle.conv1d_replicate(x, w2, b2)
     assert np.abs(y - y2).max() < 1e-5 * np.abs(y).max() + 1e-5
+
+
+@pytest.mark.parametrize("name", ["pair_l128_wma4", "ensemble_l64_degenerate"])
+def test_torch_path_matches_reference(name):
+    """oracle/torch_path.py (the CPU-baseline restatement) against the reference's outputs."""
+    from oracle import torch_path
+    c = load_case(name)
+    states, prob = torch_path.predict_loop(case_state_dicts(c), c["data"], w_ma=int(c["w_ma"]))
+    assert np.abs(prob - c["prob_detect"]).max() < 1e-6
+    assert (states == c["states"]).mean() >= 0.999
