@@ -28,7 +28,6 @@ int fail(int code, const std::string& msg) {
     } while (0)
 
 constexpr int C1 = 64, C2 = 128;  // core.py:37 mid_channels default; CamAL.eval ignores kwargs (:386-390)
-constexpr int NT = 4;
 
 // The 9 ConvBlocks of one member: (Cin, Cout, k) with k<0 meaning "the member's kernel size".
 struct ConvShape { int cin, cout, k; };
@@ -46,6 +45,15 @@ size_t blob_floats(int k) {
     n += 2 * C2 + 2;       // head
     return n;
 }
+
+// Tile configuration per precision (see conv_kernel): fp32 runs 8 compute waves x 2 column
+// tiles (one workgroup per CU, two waves per SIMD); bf16 4 compute waves x 4 column tiles
+// (two workgroups per CU).
+template <typename DT> struct TileCfg;
+template <> struct TileCfg<float> { static constexpr int NWC = 8, NT = 2; };
+template <> struct TileCfg<__bf16> { static constexpr int NWC = 4, NT = 4; };
+template <typename DT, int CIN, int COUT>
+using Geom = ConvGeom<DT, CIN, COUT, TileCfg<DT>::NT, TileCfg<DT>::NWC>;
 
 struct Layer {
     int cin = 0, cout = 0, ks = 0;
@@ -69,6 +77,8 @@ struct ProfRec { int cls; hipEvent_t a, b; };
 
 struct camal_ctx {
     int device = 0, E = 0, precision = 0, chunk = 256, cam_row = 1;
+    int num_cu = 256;
+    size_t lds_per_cu = 160 * 1024;
     std::vector<Member> m;
     std::vector<void*> owned;  // device allocations freed in destroy
     // workspace
@@ -149,7 +159,8 @@ size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 size_t workspace_layout(const camal_ctx* c, int BC, int L, Workspace* w, char* base) {
     const size_t es = c->precision == CAMAL_FP32 ? 4 : 2;
     const size_t n64 = align_up((size_t)BC * L * C1 * es), n128 = align_up((size_t)BC * L * C2 * es);
-    const int ntiles = (L + 127) / 128;
+    const int head_tn = c->precision == CAMAL_FP32 ? Geom<float, C2, C2>::TN : Geom<__bf16, C2, C2>::TN;
+    const int ntiles = (L + head_tn - 1) / head_tn;
     size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += bytes; return (void*)p; };
     Workspace t;
@@ -200,19 +211,22 @@ struct ProfScope {
 template <typename DT, int CIN, int COUT, bool RELU, bool HAS_RES, bool HEAD>
 int launch_conv(camal_ctx* c, hipStream_t s, const Layer& ly, const void* in, const void* res, void* out,
                 const float* wfc, float* cam, float* part, int BC, int L) {
-    constexpr int MT = COUT / 32, NG = 4 / MT, TN = NG * NT * 32;
-    auto kern = conv_kernel<DT, CIN, COUT, NT, RELU, HAS_RES, HEAD>;
-    size_t lds = (size_t)(TN + ly.ks - 1) * CIN * sizeof(DT);
-    if (HEAD) lds = std::max(lds, (size_t)MT * TN * 2 * sizeof(float));
+    using G = Geom<DT, CIN, COUT>;
+    auto kern = conv_kernel<DT, CIN, COUT, TileCfg<DT>::NT, TileCfg<DT>::NWC, RELU, HAS_RES, HEAD>;
+    const size_t lds = 2 * (size_t)G::buf_bytes(ly.ks) + (HEAD ? G::HEAD_BYTES : 0);
     static size_t attr_set = 0;  // per instantiation
     if (lds > attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = lds;
     }
-    dim3 grid((L + TN - 1) / TN, BC);
+    const int tpw = (L + G::TN - 1) / G::TN;
+    const long long total = (long long)tpw * BC;
+    if (total > 0x7fffffffLL) return fail(CAMAL_ERR_ARG, "too many tiles in one pass");
+    const int per_cu = std::max(1, std::min(4, (int)(c->lds_per_cu / lds)));
+    const int grid = (int)std::min<long long>(total, (long long)c->num_cu * per_cu);
     ProfScope ps(c, s, HEAD ? 2 : 1);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const DT*)in, (const uint4*)ly.wpack, ly.bias, (const DT*)res,
-                       (DT*)out, wfc, cam, part, L, ly.ks, c->cam_row);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(G::THREADS), lds, s, (const DT*)in, (const uint4*)ly.wpack, ly.bias,
+                       (const DT*)res, (DT*)out, wfc, cam, part, L, ly.ks, c->cam_row, tpw, (int)total);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -291,6 +305,8 @@ int camal_create(int device_id, int n_members, const int* kernel_sizes, int prec
     HIP_TRY(hipSetDevice(device_id));
     camal_ctx* c = new camal_ctx();
     c->device = device_id; c->E = n_members; c->precision = precision;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
     c->m.resize(n_members);
     for (int e = 0; e < n_members; ++e) c->m[e].k = kernel_sizes[e];
     *out = c;

@@ -123,171 +123,240 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
 
 // ---------------------------------------------------------------------------------------
 // Implicit-GEMM Conv1d(replicate) + folded BN + [ReLU] + [residual add] on MFMA.
-// 4 waves; wave w owns out-channel tile (w % MT) and NT column tiles of 32 timesteps.
+//
+// Persistent workgroups of 5 waves.  Waves 0-3 compute: wave w owns out-channel tile
+// (w % MT) and NT column tiles of 32 timesteps.  Wave 4 is a LOADER: while the others run
+// the MFMA loop on tile i from one LDS buffer it streams tile i+1 (+ its k-1 halo rows)
+// into the other with global_load_lds (LDS-DMA, no VGPRs), so HBM latency never sits in
+// front of the matrix pipe and the loader's vmcnt does not serialise the compute waves'
+// weight loads.  One workgroup barrier per tile hands the buffers over.
 //   HEAD = false: writes out[b][t][co]   (+ res[b][t][co] added AFTER the ReLU, :56-59)
 //   HEAD = true : last ConvBlock; the 128 x L feature map is never written.  Emits the two
-//                 CAM rows' values W_fc[k] . relu(.) per timestep: cam[b][t] for k = 1
+//                 CAM rows' values W_fc[k] . relu(.) per timestep: cam[b][t] for k = cam_row
 //                 (class_activation_map.py:42-48) and per-tile sums over t of both rows
 //                 (mean_t(W_fc[k].F) + b_k == Linear(mean_t F), camal_resnet.py:23).
 // ---------------------------------------------------------------------------------------
-template <typename DT, int CIN, int COUT, int NT, bool RELU, bool HAS_RES, bool HEAD>
-__global__ __launch_bounds__(256, 2) void conv_kernel(const DT* __restrict__ in,     // [B][L][CIN]
-                                                      const uint4* __restrict__ wpack,
-                                                      const float* __restrict__ bias,  // [COUT]
-                                                      const DT* __restrict__ res,    // [B][L][COUT]
-                                                      DT* __restrict__ out,          // [B][L][COUT]
-                                                      const float* __restrict__ wfc, // [2][COUT]
-                                                      float* __restrict__ cam_out,   // [B][L]
-                                                      float* __restrict__ part_out,  // [B][gridDim.x][2]
-                                                      int L, int ks, int cam_row) {
-    constexpr int ES = sizeof(DT);
-    constexpr int RB = CIN * ES;                 // LDS row bytes
-    constexpr int CPR = RB / 16;                 // 16-byte chunks per row
-    constexpr int NCP = CIN / Elem<DT>::K_PER_PAIR;  // chunk pairs per tap
-    constexpr int MT = COUT / 32;                // out-channel tiles
-    constexpr int NG = 4 / MT;                   // column groups across waves
-    constexpr int TN = NG * NT * 32;             // timesteps per workgroup
-    static_assert(MT == 2 || MT == 4, "COUT must be 64 or 128");
-    extern __shared__ __attribute__((aligned(16))) char lds[];
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+    // LDS destination = wave-uniform base + lane * 16; the global source is per lane.
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+template <typename DT, int CIN, int COUT, int NT, int NWC>
+struct ConvGeom {
+    static constexpr int ES = sizeof(DT);
+    static constexpr int RB = CIN * ES;                        // LDS row bytes
+    static constexpr int CPR = RB / 16;                        // 16-byte chunks per row
+    static constexpr int NCP = CIN / Elem<DT>::K_PER_PAIR;     // chunk pairs per tap
+    static constexpr int MT = COUT / 32;                       // out-channel tiles
+    static constexpr int NG = NWC / MT;                        // column groups across compute waves
+    static constexpr int THREADS = (NWC + 1) * 64;             // + the loader wave
+    static constexpr int TN = NG * NT * 32;                    // timesteps per tile
+    static constexpr int HEAD_BYTES = (MT * TN * 2 + 2 * NWC) * 4;  // CAM-head reduction scratch
+    __host__ __device__ static constexpr int buf_bytes(int ks) { return (((TN + ks - 1) * RB) + 1023) & ~1023; }
+};
+
+template <typename DT, int CIN, int COUT, int NT, int NWC, bool RELU, bool HAS_RES, bool HEAD>
+__global__ __launch_bounds__((NWC + 1) * 64) void conv_kernel(const DT* __restrict__ in,     // [B][L][CIN]
+                                                            const uint4* __restrict__ wpack,
+                                                            const float* __restrict__ bias,  // [COUT]
+                                                            const DT* __restrict__ res,    // [B][L][COUT]
+                                                            DT* __restrict__ out,          // [B][L][COUT]
+                                                            const float* __restrict__ wfc, // [2][COUT]
+                                                            float* __restrict__ cam_out,   // [B][L]
+                                                            float* __restrict__ part_out,  // [B][tiles_per_window][2]
+                                                            int L, int ks, int cam_row, int tiles_per_window,
+                                                            int total_tiles) {
+    using G = ConvGeom<DT, CIN, COUT, NT, NWC>;
+    constexpr int RB = G::RB, CPR = G::CPR, NCP = G::NCP, MT = G::MT, TN = G::TN;
+    static_assert(MT == 2 || MT == 4, "COUT must be 64 or 128");
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pad = ks >> 1;
+    const int bufb = G::buf_bytes(ks);
+    float* red = reinterpret_cast<float*>(lds + 2 * bufb);  // HEAD only
+
+    if (wave == NWC) {
+        // ------------------------------ loader wave ------------------------------------
+        const int pieces = bufb >> 10;
+        auto stage = [&](int tile, char* buf) {
+            const int b = tile / tiles_per_window, t0 = (tile - b * tiles_per_window) * TN;
+            const char* inb = reinterpret_cast<const char*>(in + (size_t)b * L * CIN);
+            for (int pc = 0; pc < pieces; ++pc) {
+                const int q = pc * 64 + lane;
+                const int row = q / CPR, c = (q % CPR) ^ swz<CPR>(row);
+                int p = t0 - pad + row;  // replicate padding of THIS layer = clamp of the source row
+                p = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
+                glds16(inb + (size_t)p * RB + c * 16, buf + pc * 1024);
+            }
+        };
+        int tile = blockIdx.x;
+        if (tile < total_tiles) stage(tile, lds);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int it = 0; tile < total_tiles; ++it, tile += gridDim.x) {
+            const int next = tile + gridDim.x;
+            if (next < total_tiles) stage(next, lds + ((it + 1) & 1) * bufb);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (HEAD) { __syncthreads(); __syncthreads(); }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---------------------------------- compute waves --------------------------------------
     const int mt = wave % MT, ng = wave / MT;
     const int r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.y, t0 = blockIdx.x * TN, pad = ks >> 1;
-    const int TR = TN + ks - 1;
-
-    // ---- stage the input tile (+halo) into LDS, clamped = replicate padding of THIS layer
-    {
-        const char* inb = reinterpret_cast<const char*>(in + (size_t)b * L * CIN);
-        const int nchunks = TR * CPR;
-        for (int q = threadIdx.x; q < nchunks; q += 256) {
-            int row = q / CPR, c = q % CPR;
-            int p = t0 - pad + row;
-            p = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
-            uint4 v = *reinterpret_cast<const uint4*>(inb + (size_t)p * RB + c * 16);
-            *reinterpret_cast<uint4*>(lds + row * RB + ((c ^ swz<CPR>(row)) << 4)) = v;
-        }
-    }
-    __syncthreads();
-
-    f32x16 acc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
-
-    // ---- K loop: taps x chunk pairs.  A fragment (weights) streams from L2 in packed
-    //      order, one coalesced 1 KiB read per wave and chunk pair, prefetched one ahead.
     const uint4* wp = wpack + (size_t)mt * ks * NCP * 64 + lane;
     const int total = ks * NCP;
     const int R0 = ng * NT * 32 + r;
-    uint4 a_cur = wp[0];
-    for (int j = 0; j < ks; ++j) {
-        const int row = R0 + j;
-        const int s = swz<CPR>(row);
-        const char* rowp = lds + row * RB;
+
+    float bv[4][4];
 #pragma unroll
-        for (int cp = 0; cp < NCP; ++cp) {
-            int idx = j * NCP + cp + 1;
-            idx = idx < total ? idx : total - 1;
-            uint4 a_nxt = wp[(size_t)idx * 64];
-            const int col = ((2 * cp + h) ^ s) << 4;
+    for (int g = 0; g < 4; ++g) load4(bias + 32 * mt + 8 * g + 4 * h, bv[g]);
+
+    __syncthreads();  // first tile has landed
+    int it = 0;
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x, ++it) {
+        const char* buf = lds + (it & 1) * bufb;
+        const int b = tile / tiles_per_window, tx = tile - b * tiles_per_window, t0 = tx * TN;
+
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+
+        // ---- K loop: taps x chunk pairs, software-pipelined by hand.  A fragments (weights) stream
+        //      from L2 in packed order (one coalesced 1 KiB read per wave and chunk pair) through a
+        //      register ring that keeps AR-1 loads in flight; B fragments (activations) are read
+        //      from LDS one chunk pair ahead into the other half of bq[2][NT].  hipcc otherwise
+        //      sinks every load to just before its use (vmcnt(0) in front of each MFMA group), so
+        //      the issue order is pinned with sched_barrier.  Ring slots are static after unrolling.
+        constexpr int AR = sizeof(DT) == 4 ? 2 : 4;
+        static_assert(NCP % AR == 0 && NCP % 2 == 0, "ring sizes must divide the chunk pairs per tap");
+        uint4 a[AR];
+        uint4 bq[2][NT];
+#pragma unroll
+        for (int d = 0; d < AR - 1; ++d) a[d] = wp[(size_t)(d < total ? d : total - 1) * 64];
+        {
+            const char* rowp = buf + R0 * RB;
+            const int col = (h ^ swz<CPR>(R0)) << 4;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bq[0][nt] = *reinterpret_cast<const uint4*>(rowp + nt * 32 * RB + col);
+        }
+        for (int j = 0; j < ks; ++j) {
+            const int row = R0 + j, rown = R0 + (j + 1 < ks ? j + 1 : j);
+            const int s = swz<CPR>(row), sn = swz<CPR>(rown);
+            const char* rowp = buf + row * RB;
+            const char* rowpn = buf + rown * RB;
+#pragma unroll
+            for (int cp = 0; cp < NCP; ++cp) {
+                int idx = j * NCP + cp + (AR - 1);
+                idx = idx < total ? idx : total - 1;
+                a[(cp + AR - 1) % AR] = wp[(size_t)idx * 64];
+                {
+                    const char* rp = cp + 1 < NCP ? rowp : rowpn;
+                    const int col = cp + 1 < NCP ? ((2 * (cp + 1) + h) ^ s) << 4 : (h ^ sn) << 4;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        bq[(cp + 1) & 1][nt] = *reinterpret_cast<const uint4*>(rp + nt * 32 * RB + col);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) mma_chunk(a[cp % AR], bq[cp & 1][nt], acc[nt], DT());
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+
+        // ---- epilogue.  acc[nt][reg]: column t = tile + r, row co = 32 mt + (reg&3) + 8 (reg>>2) + 4 h
+        if constexpr (!HEAD) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                uint4 bv = *reinterpret_cast<const uint4*>(rowp + nt * 32 * RB + col);
-                mma_chunk(a_cur, bv, acc[nt], DT());
+                const int t = t0 + (ng * NT + nt) * 32 + r;
+                if (t < L) {
+                    const size_t o = ((size_t)b * L + t) * COUT + 32 * mt + 4 * h;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float v[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            v[i] = acc[nt][4 * g + i] + bv[g][i];
+                            if (RELU) v[i] = fmaxf(v[i], 0.f);
+                        }
+                        if constexpr (HAS_RES) {
+                            float rv[4];
+                            load4(res + o + 8 * g, rv);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] += rv[i];
+                        }
+                        store4(out + o + 8 * g, v[0], v[1], v[2], v[3]);
+                    }
+                }
             }
-            a_cur = a_nxt;
-        }
-    }
-
-    // ---- epilogue.  acc[nt][reg]: column t = tile + r, row co = 32 mt + (reg&3) + 8 (reg>>2) + 4 h
-    if constexpr (!HEAD) {
-        float bv[4][4];
+        } else {
+            float w0[4][4], w1[4][4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) load4(bias + 32 * mt + 8 * g + 4 * h, bv[g]);
+            for (int g = 0; g < 4; ++g) {
+                load4(wfc + 32 * mt + 8 * g + 4 * h, w0[g]);
+                load4(wfc + COUT + 32 * mt + 8 * g + 4 * h, w1[g]);
+            }
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int t = t0 + (ng * NT + nt) * 32 + r;
-            if (t < L) {
-                const size_t o = ((size_t)b * L + t) * COUT + 32 * mt + 4 * h;
+            for (int nt = 0; nt < NT; ++nt) {
+                float c0 = 0.f, c1 = 0.f;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float v[4];
+                for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        v[i] = acc[nt][4 * g + i] + bv[g][i];
-                        if (RELU) v[i] = fmaxf(v[i], 0.f);
+                        float f = fmaxf(acc[nt][4 * g + i] + bv[g][i], 0.f);
+                        c0 = fmaf(w0[g][i], f, c0);
+                        c1 = fmaf(w1[g][i], f, c1);
                     }
-                    if constexpr (HAS_RES) {
-                        float rv[4];
-                        load4(res + o + 8 * g, rv);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] += rv[i];
-                    }
-                    store4(out + o + 8 * g, v[0], v[1], v[2], v[3]);
+                c0 += __shfl_xor(c0, 32);
+                c1 += __shfl_xor(c1, 32);
+                if (h == 0) {
+                    const int tl = (ng * NT + nt) * 32 + r;
+                    red[(mt * TN + tl) * 2 + 0] = c0;
+                    red[(mt * TN + tl) * 2 + 1] = c1;
                 }
             }
-        }
-    } else {
-        float bv[4][4], w0[4][4], w1[4][4];
+            __syncthreads();
+            float s0 = 0.f, s1 = 0.f;
+            for (int tl = threadIdx.x; tl < TN; tl += NWC * 64) {
+                float c0 = 0.f, c1 = 0.f;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            load4(bias + 32 * mt + 8 * g + 4 * h, bv[g]);
-            load4(wfc + 32 * mt + 8 * g + 4 * h, w0[g]);
-            load4(wfc + COUT + 32 * mt + 8 * g + 4 * h, w1[g]);
-        }
-        __syncthreads();  // every wave is done reading the activation tile: reuse LDS
-        float* red = reinterpret_cast<float*>(lds);  // [MT][TN][2]
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            float c0 = 0.f, c1 = 0.f;
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float f = fmaxf(acc[nt][4 * g + i] + bv[g][i], 0.f);
-                    c0 = fmaf(w0[g][i], f, c0);
-                    c1 = fmaf(w1[g][i], f, c1);
+                for (int m = 0; m < MT; ++m) {
+                    c0 += red[(m * TN + tl) * 2 + 0];
+                    c1 += red[(m * TN + tl) * 2 + 1];
                 }
-            c0 += __shfl_xor(c0, 32);
-            c1 += __shfl_xor(c1, 32);
-            if (h == 0) {
-                const int tl = (ng * NT + nt) * 32 + r;
-                red[(mt * TN + tl) * 2 + 0] = c0;
-                red[(mt * TN + tl) * 2 + 1] = c1;
+                const int t = t0 + tl;
+                if (t < L) {
+                    cam_out[(size_t)b * L + t] = cam_row ? c1 : c0;
+                    s0 += c0;
+                    s1 += c1;
+                }
             }
-        }
-        __syncthreads();
-        float s0 = 0.f, s1 = 0.f;
-        for (int tl = threadIdx.x; tl < TN; tl += 256) {
-            float c0 = 0.f, c1 = 0.f;
+            // tile sums of both rows: wave shuffle tree, then NWC partials through LDS
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                c0 += red[(m * TN + tl) * 2 + 0];
-                c1 += red[(m * TN + tl) * 2 + 1];
+            for (int o = 32; o > 0; o >>= 1) {
+                s0 += __shfl_xor(s0, o);
+                s1 += __shfl_xor(s1, o);
             }
-            const int t = t0 + tl;
-            if (t < L) {
-                cam_out[(size_t)b * L + t] = cam_row ? c1 : c0;
-                s0 += c0;
-                s1 += c1;
-            }
-        }
-        // block sum of (s0, s1): wave shuffle tree, then 4 partials through LDS
+            float* red2 = red + MT * TN * 2;
+            if (lane == 0) { red2[2 * wave] = s0; red2[2 * wave + 1] = s1; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float* po = part_out + ((size_t)b * tiles_per_window + tx) * 2;
+                float p0 = 0.f, p1 = 0.f;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            s0 += __shfl_xor(s0, o);
-            s1 += __shfl_xor(s1, o);
+                for (int wv = 0; wv < NWC; ++wv) { p0 += red2[2 * wv]; p1 += red2[2 * wv + 1]; }
+                po[0] = p0;
+                po[1] = p1;
+            }
         }
-        __syncthreads();
-        if (lane == 0) { red[2 * wave] = s0; red[2 * wave + 1] = s1; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            float* po = part_out + ((size_t)b * gridDim.x + blockIdx.x) * 2;
-            po[0] = (red[0] + red[2]) + (red[4] + red[6]);
-            po[1] = (red[1] + red[3]) + (red[5] + red[7]);
-        }
+        __syncthreads();  // next tile landed (loader) and this buffer is free to refill
     }
 }
 
