@@ -273,6 +273,18 @@ __global__ __launch_bounds__((NWC + 1) * 64) void conv_kernel(const DT* __restri
 
         // ---- epilogue.  acc[nt][reg]: column t = tile + r, row co = 32 mt + (reg&3) + 8 (reg>>2) + 4 h
         if constexpr (!HEAD) {
+            // residual rows first: all loads of the tile in flight before the first add
+            float rv[HAS_RES ? NT : 1][4][4];
+            if constexpr (HAS_RES) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    int t = t0 + (ng * NT + nt) * 32 + r;
+                    t = t < L ? t : L - 1;
+                    const size_t o = ((size_t)b * L + t) * COUT + 32 * mt + 4 * h;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) load4(res + o + 8 * g, rv[nt][g]);
+                }
+            }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int t = t0 + (ng * NT + nt) * 32 + r;
@@ -285,12 +297,7 @@ __global__ __launch_bounds__((NWC + 1) * 64) void conv_kernel(const DT* __restri
                         for (int i = 0; i < 4; ++i) {
                             v[i] = acc[nt][4 * g + i] + bv[g][i];
                             if (RELU) v[i] = fmaxf(v[i], 0.f);
-                        }
-                        if constexpr (HAS_RES) {
-                            float rv[4];
-                            load4(res + o + 8 * g, rv);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) v[i] += rv[i];
+                            if constexpr (HAS_RES) v[i] += rv[nt][g][i];
                         }
                         store4(out + o + 8 * g, v[0], v[1], v[2], v[3]);
                     }

@@ -1,0 +1,78 @@
+"""Multi-GPU layer: one process per GPU (``torch.distributed``; backend "nccl" = RCCL on ROCm,
+"gloo" in CPU tests).
+
+Inference: windows are independent units — ``[N,L]`` is cut into ``world``
+contiguous row blocks (``N // world`` each, remainder to the last), every rank runs the whole
+ensemble on its block, NO collective touches the data path.
+
+Training: data-parallel per member like the reference's ``nn.DataParallel``
+(``torch_trainer.py:82-90``): per-rank BatchNorm batch statistics, and ONE all-reduce (sum,
+then divide by world) of a single flat fp32 gradient bucket per step (2-4 MB: latency-bound on
+xGMI, so one fused call instead of per-parameter buckets).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+
+def world_info():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def shard_bounds(n: int, world: int, rank: int):
+    """[start, end) of rank's contiguous block of n windows."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    per = n // world
+    start = rank * per
+    end = n if rank == world - 1 else start + per
+    return start, end
+
+
+def predict_sharded(camal, data, rank=None, world=None, **kw):
+    """This rank's slice of ``camal.predict(data)``: returns (start, end, result) where result is
+    what ``predict`` returns for rows [start, end).  No communication."""
+    r, _, w = world_info()
+    rank = r if rank is None else rank
+    world = w if world is None else world
+    data = np.asarray(data)
+    if data.ndim == 1:
+        data = data[None, :]
+    s, e = shard_bounds(len(data), world, rank)
+    if e == s:
+        return s, e, None
+    return s, e, camal.predict(data[s:e], **kw)
+
+
+def gather_shards(parts, n, dist=None):
+    """Optional convenience for small outputs: all-gather per-rank NumPy blocks (object gather;
+    control path only — large results should stay where they were produced)."""
+    if dist is None or not dist.is_initialized():
+        return parts
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, parts)
+    return out
+
+
+def allreduce_mean_(flat: torch.Tensor, dist=None):
+    """In-place mean over ranks of the flat gradient bucket (one collective per step)."""
+    if dist is None:
+        import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return flat
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.div_(dist.get_world_size())
+    return flat
+
+
+def max_over_ranks(value: float, device=None, dist=None) -> float:
+    if dist is None:
+        import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
