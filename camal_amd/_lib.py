@@ -36,6 +36,12 @@ SIGNATURES = {
     "camal_localize": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "camal_postprocess": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _vp, _vp, _vp, _vp, _vp]),
     "camal_attention": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "camal_trainer_param_count": (_sz, [_i]),
+    "camal_trainer_running_count": (_sz, []),
+    "camal_trainer_create": (_i, [_i, _i, _i, _i, C.POINTER(_vp)]),
+    "camal_trainer_destroy": (_i, [_vp]),
+    "camal_train_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, C.c_float, _vp, _vp, _vp, _vp, _vp]),
+    "camal_adamw_step": (_i, [_vp, _vp, _vp, _vp, _sz, _i, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
     "camal_set_profiling": (_i, [_vp, _i]),
     "camal_get_profile": (_i, [_vp, C.POINTER(_i), C.POINTER(_d)]),
 }

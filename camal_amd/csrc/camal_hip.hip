@@ -52,8 +52,12 @@ size_t blob_floats(int k) {
 template <typename DT> struct TileCfg;
 template <> struct TileCfg<float> { static constexpr int NWC = 8, NT = 2; };
 template <> struct TileCfg<__bf16> { static constexpr int NWC = 4, NT = 4; };
+// fp32 128 -> 64 (only the dgrad of block 2's first conv): 512-byte rows and 256-step tiles
+// would not fit two LDS buffers, so one column tile per wave.
+template <typename DT, int CIN, int COUT> struct TileNT { static constexpr int NT = TileCfg<DT>::NT; };
+template <> struct TileNT<float, 128, 64> { static constexpr int NT = 1; };
 template <typename DT, int CIN, int COUT>
-using Geom = ConvGeom<DT, CIN, COUT, TileCfg<DT>::NT, TileCfg<DT>::NWC>;
+using Geom = ConvGeom<DT, CIN, COUT, TileNT<DT, CIN, COUT>::NT, TileCfg<DT>::NWC>;
 
 struct Layer {
     int cin = 0, cout = 0, ks = 0;
@@ -208,27 +212,40 @@ struct ProfScope {
 };
 
 // ---- launches -------------------------------------------------------------------------
+// L_out: output rows per window; input rows per window L_in, input row for (t, tap j) = t + j - in_off;
+// zero_row == nullptr: out-of-range rows replicate the edge (forward), else they read zeros (dgrad).
 template <typename DT, int CIN, int COUT, bool RELU, bool HAS_RES, bool HEAD>
-int launch_conv(camal_ctx* c, hipStream_t s, const Layer& ly, const void* in, const void* res, void* out,
-                const float* wfc, float* cam, float* part, int BC, int L) {
+int launch_conv_ex(camal_ctx* c, int num_cu, size_t lds_per_cu, int cam_row, hipStream_t s, const void* wpack,
+                   const float* bias, int ks, const void* in, const void* res, void* out, const float* wfc, float* cam,
+                   float* part, int BC, int L_out, int L_in, int in_off, const void* zero_row) {
     using G = Geom<DT, CIN, COUT>;
-    auto kern = conv_kernel<DT, CIN, COUT, TileCfg<DT>::NT, TileCfg<DT>::NWC, RELU, HAS_RES, HEAD>;
-    const size_t lds = 2 * (size_t)G::buf_bytes(ly.ks) + (HEAD ? G::HEAD_BYTES : 0);
+    auto kern = conv_kernel<DT, CIN, COUT, G::TN / (32 * G::NG), TileCfg<DT>::NWC, RELU, HAS_RES, HEAD>;
+    const size_t lds = 2 * (size_t)G::buf_bytes(ks) + (HEAD ? G::HEAD_BYTES : 0);
+    if (lds > lds_per_cu) return fail(CAMAL_ERR_ARG, "kernel size too large for the LDS tile");
     static size_t attr_set = 0;  // per instantiation
     if (lds > attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = lds;
     }
-    const int tpw = (L + G::TN - 1) / G::TN;
+    const int tpw = (L_out + G::TN - 1) / G::TN;
     const long long total = (long long)tpw * BC;
     if (total > 0x7fffffffLL) return fail(CAMAL_ERR_ARG, "too many tiles in one pass");
-    const int per_cu = std::max(1, std::min(4, (int)(c->lds_per_cu / lds)));
-    const int grid = (int)std::min<long long>(total, (long long)c->num_cu * per_cu);
+    const int per_cu = std::max(1, std::min(4, (int)(lds_per_cu / lds)));
+    const int grid = (int)std::min<long long>(total, (long long)num_cu * per_cu);
     ProfScope ps(c, s, HEAD ? 2 : 1);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(G::THREADS), lds, s, (const DT*)in, (const uint4*)ly.wpack, ly.bias,
-                       (const DT*)res, (DT*)out, wfc, cam, part, L, ly.ks, c->cam_row, tpw, (int)total);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(G::THREADS), lds, s, (const DT*)in, (const uint4*)wpack, bias,
+                       (const DT*)res, (DT*)out, wfc, cam, part, L_out, ks, cam_row, tpw, (int)total, L_in, in_off,
+                       (const DT*)zero_row);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+template <typename DT, int CIN, int COUT, bool RELU, bool HAS_RES, bool HEAD>
+int launch_conv(camal_ctx* c, hipStream_t s, const Layer& ly, const void* in, const void* res, void* out,
+                const float* wfc, float* cam, float* part, int BC, int L) {
+    return launch_conv_ex<DT, CIN, COUT, RELU, HAS_RES, HEAD>(c, c->num_cu, c->lds_per_cu, c->cam_row, s, ly.wpack,
+                                                              ly.bias, ly.ks, in, res, out, wfc, cam, part, BC, L, L,
+                                                              ly.ks >> 1, nullptr);
 }
 
 // One member's conv stack on BC windows: x -> cam row 1 [BC][L] + pooled partials [BC][ntiles][2]
@@ -478,3 +495,5 @@ int camal_get_profile(camal_ctx* c, int* launches, double* ms) {
 }
 
 }  // extern "C"
+
+#include "camal_train_impl.hpp"

@@ -166,7 +166,12 @@ __global__ __launch_bounds__((NWC + 1) * 64) void conv_kernel(const DT* __restri
                                                             float* __restrict__ cam_out,   // [B][L]
                                                             float* __restrict__ part_out,  // [B][tiles_per_window][2]
                                                             int L, int ks, int cam_row, int tiles_per_window,
-                                                            int total_tiles) {
+                                                            int total_tiles,
+                                                            // generalisation used by the training path (dgrad):
+                                                            // input row for (output t, tap j) = t + j - in_off,
+                                                            // valid in [0, L_in); outside: clamp (replicate) or,
+                                                            // if zero_row != null, a row of zeros.
+                                                            int L_in, int in_off, const DT* __restrict__ zero_row) {
     using G = ConvGeom<DT, CIN, COUT, NT, NWC>;
     constexpr int RB = G::RB, CPR = G::CPR, NCP = G::NCP, MT = G::MT, TN = G::TN;
     static_assert(MT == 2 || MT == 4, "COUT must be 64 or 128");
@@ -174,7 +179,6 @@ __global__ __launch_bounds__((NWC + 1) * 64) void conv_kernel(const DT* __restri
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pad = ks >> 1;
     const int bufb = G::buf_bytes(ks);
     float* red = reinterpret_cast<float*>(lds + 2 * bufb);  // HEAD only
 
@@ -183,13 +187,16 @@ __global__ __launch_bounds__((NWC + 1) * 64) void conv_kernel(const DT* __restri
         const int pieces = bufb >> 10;
         auto stage = [&](int tile, char* buf) {
             const int b = tile / tiles_per_window, t0 = (tile - b * tiles_per_window) * TN;
-            const char* inb = reinterpret_cast<const char*>(in + (size_t)b * L * CIN);
+            const char* inb = reinterpret_cast<const char*>(in + (size_t)b * L_in * CIN);
             for (int pc = 0; pc < pieces; ++pc) {
                 const int q = pc * 64 + lane;
                 const int row = q / CPR, c = (q % CPR) ^ swz<CPR>(row);
-                int p = t0 - pad + row;  // replicate padding of THIS layer = clamp of the source row
-                p = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
-                glds16(inb + (size_t)p * RB + c * 16, buf + pc * 1024);
+                const int p = t0 - in_off + row;
+                // replicate padding of THIS layer = clamp of the source row (camal_resnet.py:83)
+                const int pcl = p < 0 ? 0 : (p > L_in - 1 ? L_in - 1 : p);
+                const char* src = inb + (size_t)pcl * RB + c * 16;
+                if (zero_row != nullptr && pcl != p) src = reinterpret_cast<const char*>(zero_row) + c * 16;
+                glds16(src, buf + pc * 1024);
             }
         };
         int tile = blockIdx.x;

@@ -1,0 +1,478 @@
+// camal_train_kernels.hpp — gfx950 device code for the training step of one CamAL ResNet
+// (reference: BasedClassifTrainer.__train, src/helpers/torch_trainer.py:273-300, on
+// CamALResNet in train() mode, src/models/camal/classifiers/camal_resnet.py).
+//
+// All tensors fp32, activations [window][time][channel].  Convolutions (forward, dgrad) reuse
+// conv_kernel from camal_kernels.hpp; this file adds BatchNorm-train statistics / apply /
+// backward, the pooled head + cross-entropy, the MFMA weight-gradient kernel, the Cin=1 stem
+// kernels and AdamW.  Every cross-workgroup reduction is two-stage through a partial buffer
+// with a fixed summation order, so a step is bitwise reproducible.
+#pragma once
+#include "camal_kernels.hpp"
+
+namespace camal {
+
+// ---- weight re-layout on the device (weights change every step) -------------------------
+// w [Cout][Cin][ks] -> MFMA A-fragment order of conv_kernel<float>:
+//   [mt][tap][chunk pair][lane][4]  with lane (i = l&31, h = l>>5), element s
+//   flip == 0 (forward):  W'[co' = 32 mt + i][ci' = 8 cp + 4 h + s][tap]        = w[co'][ci'][tap]
+//   flip == 1 (dgrad): the adjoint conv has Cout' = Cin, Cin' = Cout and a reversed kernel:
+//                         W'[co'][ci'][tap] = w[ci'][co'][ks - 1 - tap]
+__global__ void pack_w_kernel(const float* __restrict__ w, float* __restrict__ out, int coutp, int cinp, int ks,
+                              int flip) {
+    const int total = coutp * cinp * ks;
+    const int ncp = cinp / 8;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int s = idx & 3, l = (idx >> 2) & 63;
+        int rest = idx >> 8;
+        const int cp = rest % ncp; rest /= ncp;
+        const int j = rest % ks;
+        const int mt = rest / ks;
+        const int co = 32 * mt + (l & 31), ci = 8 * cp + 4 * (l >> 5) + s;
+        out[idx] = flip ? w[((size_t)ci * coutp + co) * ks + (ks - 1 - j)] : w[((size_t)co * cinp + ci) * ks + j];
+    }
+}
+
+// ---- stem, train mode: raw conv outputs of the two Cin = 1 layers --------------------------
+//   z0[t][co] = b[co] + sum_j w[co][j] x[clamp(t + j - k/2)]     (ConvBlock 0 of block 1)
+//   zr[t][co] = br[co] + wr[co] x[t]                              (residual conv of block 1)
+__global__ __launch_bounds__(256) void stem_train_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, const float* __restrict__ wr,
+                                                         const float* __restrict__ br, float* __restrict__ z0,
+                                                         float* __restrict__ zr, int L, int ks) {
+    __shared__ float xs[64 + 64];
+    const int b = blockIdx.y, t0 = blockIdx.x * 64, pad = ks >> 1;
+    const float* xb = x + (size_t)b * L;
+    for (int i = threadIdx.x; i < 64 + ks - 1; i += 256) {
+        int p = t0 - pad + i;
+        p = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
+        xs[i] = xb[p];
+    }
+    __syncthreads();
+    const int cg = threadIdx.x & 15, tq = threadIdx.x >> 4;
+    float acc[4][4], bv[4], wrv[4], brv[4];
+    load4(bias + 4 * cg, bv); load4(wr + 4 * cg, wrv); load4(br + 4 * cg, brv);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[q][c] = bv[c];
+    for (int j = 0; j < ks; ++j) {
+        float wv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wv[c] = w[(4 * cg + c) * ks + j];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float xv = xs[tq + 16 * q + j];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[q][c] = fmaf(wv[c], xv, acc[q][c]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int t = t0 + tq + 16 * q;
+        if (t < L) {
+            const size_t o = ((size_t)b * L + t) * 64 + 4 * cg;
+            store4(z0 + o, acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
+            const float xv = xs[tq + 16 * q + pad];
+            store4(zr + o, fmaf(wrv[0], xv, brv[0]), fmaf(wrv[1], xv, brv[1]), fmaf(wrv[2], xv, brv[2]),
+                   fmaf(wrv[3], xv, brv[3]));
+        }
+    }
+}
+
+// ---- BatchNorm1d, train mode ------------------------------------------------------------------
+// Batch statistics over the N = B*L rows of z [N][C] (biased variance for the normalisation,
+// unbiased for the running update, momentum 0.1 — torch.nn.BatchNorm1d as used at
+// camal_resnet.py:53,84).  Stage 1: per-block partial (sum, sum of squares) in double.
+#define BN_ROWS_PER_BLOCK 256
+
+template <int C>
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ z, int N,
+                                                               double* __restrict__ partial /*[grid][C][2]*/) {
+    constexpr int G = 256 / C;
+    __shared__ double sh[256][2];
+    const int c = threadIdx.x % C, g = threadIdx.x / C;
+    const int r0 = blockIdx.x * BN_ROWS_PER_BLOCK;
+    const int r1 = min(N, r0 + BN_ROWS_PER_BLOCK);
+    float s = 0.f, ss = 0.f;
+    for (int r = r0 + g; r < r1; r += G) {
+        const float v = z[(size_t)r * C + c];
+        s += v;
+        ss = fmaf(v, v, ss);
+    }
+    sh[threadIdx.x][0] = (double)s;
+    sh[threadIdx.x][1] = (double)ss;
+    __syncthreads();
+    if (g == 0) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int k = 0; k < G; ++k) { a += sh[k * C + c][0]; b += sh[k * C + c][1]; }
+        partial[((size_t)blockIdx.x * C + c) * 2 + 0] = a;
+        partial[((size_t)blockIdx.x * C + c) * 2 + 1] = b;
+    }
+}
+
+template <int C>
+__global__ void bn_stats_final_kernel(const double* __restrict__ partial, int nblocks, int N, float eps, float momentum,
+                                      float* __restrict__ mean, float* __restrict__ invstd,
+                                      float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int g = 0; g < nblocks; ++g) { s += partial[((size_t)g * C + c) * 2]; ss += partial[((size_t)g * C + c) * 2 + 1]; }
+    const double m = s / N;
+    double var = ss / N - m * m;
+    var = var > 0.0 ? var : 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const float unbiased = (float)(N > 1 ? var * ((double)N / (double)(N - 1)) : var);
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+
+// a = [relu](bn(z)) [+ bn_r(zr)]   (ConvBlock output; block output with the skip added AFTER the ReLU)
+template <int C, bool RELU, bool HAS_RES>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ zr,
+                                                       const float* __restrict__ mean_r, const float* __restrict__ invstd_r,
+                                                       const float* __restrict__ gamma_r, const float* __restrict__ beta_r,
+                                                       float* __restrict__ out, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % (C / 4)) * 4;
+        float v[4], m[4], is[4], g[4], bt[4], o[4];
+        load4(z + i * 4, v); load4(mean + c, m); load4(invstd + c, is); load4(gamma + c, g); load4(beta + c, bt);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            o[k] = (v[k] - m[k]) * is[k] * g[k] + bt[k];
+            if (RELU) o[k] = fmaxf(o[k], 0.f);
+        }
+        if constexpr (HAS_RES) {
+            load4(zr + i * 4, v); load4(mean_r + c, m); load4(invstd_r + c, is); load4(gamma_r + c, g); load4(beta_r + c, bt);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] += (v[k] - m[k]) * is[k] * g[k] + bt[k];
+        }
+        store4(out + i * 4, o[0], o[1], o[2], o[3]);
+    }
+}
+
+// BatchNorm backward, stage 1: per-channel s1 = sum dyh, s2 = sum dyh * xhat with
+// dyh = da * [bn(z) > 0] (RELU) and xhat = (z - mean) * invstd.
+// BCAST: da[b][t][c] = dpool[b][c] * inv_len (gradient of the temporal mean, camal_resnet.py:23).
+template <int C, bool RELU, bool BCAST>
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ da, const float* __restrict__ z,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             int N, int L, float inv_len, double* __restrict__ partial) {
+    constexpr int G = 256 / C;
+    __shared__ double sh[256][2];
+    const int c = threadIdx.x % C, g = threadIdx.x / C;
+    const int r0 = blockIdx.x * BN_ROWS_PER_BLOCK;
+    const int r1 = min(N, r0 + BN_ROWS_PER_BLOCK);
+    const float m = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = r0 + g; r < r1; r += G) {
+        const float xh = (z[(size_t)r * C + c] - m) * is;
+        float d = BCAST ? da[(size_t)(r / L) * C + c] * inv_len : da[(size_t)r * C + c];
+        if (RELU) d = (xh * ga + be) > 0.f ? d : 0.f;
+        s1 += d;
+        s2 = fmaf(d, xh, s2);
+    }
+    sh[threadIdx.x][0] = (double)s1;
+    sh[threadIdx.x][1] = (double)s2;
+    __syncthreads();
+    if (g == 0) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int k = 0; k < G; ++k) { a += sh[k * C + c][0]; b += sh[k * C + c][1]; }
+        partial[((size_t)blockIdx.x * C + c) * 2 + 0] = a;
+        partial[((size_t)blockIdx.x * C + c) * 2 + 1] = b;
+    }
+}
+
+template <int C>
+__global__ void bn_bwd_final_kernel(const double* __restrict__ partial, int nblocks, float* __restrict__ s1,
+                                    float* __restrict__ s2, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int g = 0; g < nblocks; ++g) { a += partial[((size_t)g * C + c) * 2]; b += partial[((size_t)g * C + c) * 2 + 1]; }
+    s1[c] = (float)a;
+    s2[c] = (float)b;
+    dbeta[c] = (float)a;
+    dgamma[c] = (float)b;
+}
+
+// dz = gamma * invstd * (dyh - s1/N - xhat * s2/N)
+template <int C, bool RELU, bool BCAST>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ da, const float* __restrict__ z,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ s1, const float* __restrict__ s2,
+                                                           int N, int L, float inv_len, float* __restrict__ dz) {
+    const size_t n4 = (size_t)N * (C / 4);
+    const float invN = 1.f / (float)N;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % (C / 4)) * 4;
+        const size_t r = i / (C / 4);
+        float v[4], m[4], is[4], g[4], bt[4], d[4], a1[4], a2[4], o[4];
+        load4(z + i * 4, v); load4(mean + c, m); load4(invstd + c, is); load4(gamma + c, g); load4(beta + c, bt);
+        load4(s1 + c, a1); load4(s2 + c, a2);
+        if (BCAST) {
+            load4(da + (r / L) * C + c, d);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[k] *= inv_len;
+        } else {
+            load4(da + i * 4, d);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xh = (v[k] - m[k]) * is[k];
+            float dy = d[k];
+            if (RELU) dy = (xh * g[k] + bt[k]) > 0.f ? dy : 0.f;
+            o[k] = g[k] * is[k] * (dy - a1[k] * invN - xh * a2[k] * invN);
+        }
+        store4(dz + i * 4, o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ---- pooled head + cross-entropy (camal_resnet.py:23, torch_trainer.py:288-296) -------------------
+// One workgroup per window: pooled = mean_t F; logits = W pooled + b; softmax; CE; argmax;
+// dlogits = (p - onehot) / B; dpool = W^T dlogits.
+__global__ __launch_bounds__(256) void head_loss_kernel(const float* __restrict__ feat /*[B][L][128]*/,
+                                                        const float* __restrict__ wfc, const float* __restrict__ bfc,
+                                                        const int* __restrict__ labels, int B, int L,
+                                                        float* __restrict__ pooled /*[B][128]*/,
+                                                        float* __restrict__ dpool /*[B][128]*/,
+                                                        float* __restrict__ logits /*[B][2]*/,
+                                                        float* __restrict__ dlogits /*[B][2]*/,
+                                                        float* __restrict__ loss /*[B]*/, int* __restrict__ correct) {
+    __shared__ float sp[256];
+    __shared__ float sl[4];
+    const int b = blockIdx.x, c = threadIdx.x & 127, half = threadIdx.x >> 7;
+    const float* f = feat + (size_t)b * L * 128;
+    float s = 0.f;
+    for (int t = half; t < L; t += 2) s += f[(size_t)t * 128 + c];
+    sp[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const float p = (sp[c] + sp[c + 128]) / (float)L;
+        sp[c] = p;
+        pooled[(size_t)b * 128 + c] = p;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        float a = 0.f;
+        for (int k = 0; k < 128; ++k) a = fmaf(wfc[threadIdx.x * 128 + k], sp[k], a);
+        sl[threadIdx.x] = a + bfc[threadIdx.x];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float l0 = sl[0], l1 = sl[1];
+        const float m = fmaxf(l0, l1);
+        const float e0 = expf(l0 - m), e1 = expf(l1 - m), den = e0 + e1;
+        const float p0 = e0 / den, p1 = e1 / den;
+        const int y = labels[b];
+        loss[b] = -((y ? l1 : l0) - m - logf(den));
+        correct[b] = ((l1 > l0) ? 1 : 0) == y;
+        logits[2 * b] = l0; logits[2 * b + 1] = l1;
+        const float d0 = (p0 - (y == 0 ? 1.f : 0.f)) / (float)B, d1 = (p1 - (y == 1 ? 1.f : 0.f)) / (float)B;
+        dlogits[2 * b] = d0; dlogits[2 * b + 1] = d1;
+        sl[2] = d0; sl[3] = d1;
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) dpool[(size_t)b * 128 + c] = wfc[c] * sl[2] + wfc[128 + c] * sl[3];
+}
+
+// grads of the head and the batch loss / accuracy, fixed order over the batch (one workgroup)
+__global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restrict__ pooled, const float* __restrict__ dlogits,
+                                                          const float* __restrict__ loss, const int* __restrict__ correct,
+                                                          int B, float* __restrict__ dwfc /*[2][128]*/,
+                                                          float* __restrict__ dbfc /*[2]*/, float* __restrict__ loss_out,
+                                                          int* __restrict__ ncorrect_out) {
+    const int k = threadIdx.x >> 7, c = threadIdx.x & 127;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a = fmaf(dlogits[2 * b + k], pooled[(size_t)b * 128 + c], a);
+    dwfc[k * 128 + c] = a;
+    if (threadIdx.x < 2) {
+        float d = 0.f;
+        for (int b = 0; b < B; ++b) d += dlogits[2 * b + threadIdx.x];
+        dbfc[threadIdx.x] = d;
+    }
+    if (threadIdx.x == 2) {
+        double s = 0.0;
+        int n = 0;
+        for (int b = 0; b < B; ++b) { s += (double)loss[b]; n += correct[b]; }
+        *loss_out = (float)(s / B);
+        *ncorrect_out = n;
+    }
+}
+
+// ---- adjoint of the replicate padding ------------------------------------------------------------
+// dxp [B][L + 2 pad][C] is the gradient w.r.t. the PADDED input; positions outside [0, L) were copies
+// of the edge samples, so their gradients fold onto t = 0 and t = L - 1.
+template <int C>
+__global__ __launch_bounds__(256) void fold_edges_kernel(const float* __restrict__ dxp, float* __restrict__ dx, int B,
+                                                         int L, int pad) {
+    const size_t n4 = (size_t)B * L * (C / 4);
+    const int Lp = L + 2 * pad;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % (C / 4)) * 4;
+        const size_t r = i / (C / 4);
+        const int b = (int)(r / L), t = (int)(r % L);
+        const float* src = dxp + ((size_t)b * Lp) * C + c;
+        float v[4], o[4];
+        load4(src + (size_t)(t + pad) * C, o);
+        if (t == 0)
+            for (int q = 0; q < pad; ++q) { load4(src + (size_t)q * C, v); o[0] += v[0]; o[1] += v[1]; o[2] += v[2]; o[3] += v[3]; }
+        if (t == L - 1)
+            for (int q = L + pad; q < Lp; ++q) { load4(src + (size_t)q * C, v); o[0] += v[0]; o[1] += v[1]; o[2] += v[2]; o[3] += v[3]; }
+        store4(dx + i * 4, o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ---- weight gradient on MFMA -----------------------------------------------------------------------
+// dw[co][ci][j] = sum_{b,t} dz[b][t][co] * a[b][clamp(t + j - pad)][ci]   (adjoint of camal_resnet.py:82-83)
+// GEMM view: M = co, N = ci, K = (b, t) for every tap j.  One workgroup = COUT/32 waves (wave = one
+// 32-wide co tile) x one 32-wide ci tile x a group of <= WG_TAPS taps x a split of the batch.
+// v_mfma_f32_32x32x2_f32 consumes two timesteps per instruction: lane (i, h) feeds A = dz[2s+h][co_i]
+// and B = a[2s+h+j-pad][ci_i]; both tiles sit in LDS as plain rows, the tap is a row offset.
+// Partial results go to part[split][j][co][ci]; wgrad_reduce_kernel sums the splits in a fixed order.
+#define WG_TAPS 8
+#define WG_TT 64
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(COUT * 2) void wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ ain,
+                                                         float* __restrict__ part, int B, int L, int ks,
+                                                         int windows_per_split) {
+    constexpr int NW = COUT / 32;
+    __shared__ float s_dz[WG_TT][COUT];
+    __shared__ float s_a[WG_TT + 64][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int ci0 = blockIdx.x * 32;
+    const int j0 = blockIdx.y * WG_TAPS, ntap = min(WG_TAPS, ks - j0);
+    const int split = blockIdx.z, pad = ks >> 1;
+    const int b0 = split * windows_per_split, b1 = min(B, b0 + windows_per_split);
+
+    f32x16 acc[WG_TAPS];
+#pragma unroll
+    for (int j = 0; j < WG_TAPS; ++j)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[j][k] = 0.f;
+
+    for (int b = b0; b < b1; ++b) {
+        for (int t0 = 0; t0 < L; t0 += WG_TT) {
+            __syncthreads();
+            // dz rows t0 .. t0+TT-1 (zeros past L), all COUT channels
+            for (int q = threadIdx.x; q < WG_TT * (COUT / 4); q += COUT * 2) {
+                const int row = q / (COUT / 4), c4 = (q % (COUT / 4)) * 4;
+                const int t = t0 + row;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t < L) v = *reinterpret_cast<const float4*>(dz + ((size_t)b * L + t) * COUT + c4);
+                *reinterpret_cast<float4*>(&s_dz[row][c4]) = v;
+            }
+            // input rows t0 + j0 - pad .. (+ TT + ntap - 2), clamped = replicate padding, 32 channels
+            for (int q = threadIdx.x; q < (WG_TT + WG_TAPS - 1) * 8; q += COUT * 2) {
+                const int row = q >> 3, c4 = (q & 7) * 4;
+                int p = t0 + j0 - pad + row;
+                p = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
+                *reinterpret_cast<float4*>(&s_a[row][c4]) =
+                    *reinterpret_cast<const float4*>(ain + ((size_t)b * L + p) * CIN + ci0 + c4);
+            }
+            __syncthreads();
+#pragma unroll 2
+            for (int s = 0; s < WG_TT / 2; ++s) {
+                const float av = s_dz[2 * s + h][32 * wave + i];
+#pragma unroll
+                for (int j = 0; j < WG_TAPS; ++j)
+                    if (j < ntap) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s_a[2 * s + h + j][i], acc[j], 0, 0, 0);
+            }
+        }
+    }
+    // acc[j][reg]: column ci = ci0 + i, row co = 32 wave + (reg&3) + 8 (reg>>2) + 4 h
+#pragma unroll
+    for (int j = 0; j < WG_TAPS; ++j)
+        if (j < ntap) {
+            float* po = part + (((size_t)split * ks + (j0 + j)) * COUT + 32 * wave) * CIN + ci0 + i;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) po[(size_t)((reg & 3) + 8 * (reg >> 2) + 4 * h) * CIN] = acc[j][reg];
+        }
+}
+
+// grad[co][ci][j] = sum_split part[split][j][co][ci]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int cout, int cin, int ks,
+                                    float* __restrict__ grad) {
+    const int total = cout * cin * ks;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int ci = idx % cin, co = (idx / cin) % cout, j = idx / (cin * cout);
+        float a = 0.f;
+        for (int s = 0; s < nsplit; ++s) a += part[(size_t)s * total + idx];
+        grad[((size_t)co * cin + ci) * ks + j] = a;
+    }
+}
+
+// Cin = 1 layers: part[b][j][co] = sum_t dz[b][t][co] * x[b][clamp(t + j - pad)]   (64 out-channels)
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+                                                         float* __restrict__ part, int L, int ks) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.x, co = threadIdx.x & 63, ph = threadIdx.x >> 6, pad = ks >> 1;
+    const float* xb = x + (size_t)b * L;
+    const float* dzb = dz + (size_t)b * L * 64;
+    for (int j0 = 0; j0 < ks; j0 += 8) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int t = ph; t < L; t += 4) {
+            const float d = dzb[(size_t)t * 64 + co];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int p = t + j0 + j - pad;
+                p = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
+                acc[j] = fmaf(d, xb[p], acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            __syncthreads();
+            red[ph][co] = acc[j];
+            __syncthreads();
+            if (ph == 0 && j0 + j < ks)
+                part[((size_t)b * ks + j0 + j) * 64 + co] = (red[0][co] + red[1][co]) + (red[2][co] + red[3][co]);
+        }
+    }
+}
+
+// grad[co][j] = sum_b part[b][j][co]
+__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ part, int B, int ks, float* __restrict__ grad) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 64 * ks) return;
+    const int co = idx % 64, j = idx / 64;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += part[((size_t)b * ks + j) * 64 + co];
+    grad[co * ks + j] = a;
+}
+
+// ---- AdamW (torch.optim.AdamW defaults: torch_trainer.py:35; decoupled weight decay) -------------------
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, size_t n, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, float bias_c1, float bias_c2_sqrt) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        float pi = p[i] * (1.f - lr * weight_decay);
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bias_c2_sqrt + eps;
+        p[i] = pi - (lr / bias_c1) * (mi / denom);
+    }
+}
+
+__global__ void fill_kernel(float* __restrict__ p, size_t n, float v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+}  // namespace camal

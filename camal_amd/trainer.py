@@ -1,0 +1,372 @@
+"""``BasedClassifTrainer`` — mirror of the reference's classifier trainer
+(``src/helpers/torch_trainer.py:15-325``): same constructor / ``train`` / ``evaluate`` /
+``restore_best_weights`` / ``log`` schema, with the per-batch forward + backward + AdamW running in
+libcamal_hip.so (``camal_train_fwd_bwd`` / ``camal_adamw_step``).
+
+``all_gpu=True`` in the reference wraps the model in single-process ``nn.DataParallel``
+(:82-90).  Here multi-GPU training is one process per GPU: when ``torch.distributed`` is
+initialised, every step all-reduces ONE flat fp32 gradient bucket (mean over ranks) on RCCL
+between backward and the optimizer; BatchNorm statistics stay per rank, like DataParallel.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import time
+import warnings
+
+import numpy as np
+import torch
+
+from . import _lib, parallel, weights
+from .metrics import Classifmetrics
+
+
+class TSLoader:
+    """Minimal stand-in for ``DataLoader(TSDataset(X, y), batch_size, shuffle)``
+    (reference core.py:92-119, torch_dataset.py:197-250): yields ``(ts [b,1,L], labels [b])``
+    NumPy batches; ``shuffle=True`` draws a fresh ``torch.randperm`` per epoch from the global
+    torch RNG, like the reference's loader."""
+
+    def __init__(self, X, y, batch_size=1, shuffle=False):
+        X = np.asarray(X)
+        self.samples = X[:, None, :] if X.ndim == 2 else X
+        self.labels = np.asarray(y).ravel()
+        assert len(self.samples) == len(self.labels), (
+            f"Number of X sample {len(self.samples)} doesn't match number of y sample {len(self.labels)}.")
+        self.batch_size, self.shuffle = int(batch_size), bool(shuffle)
+
+    def __len__(self):
+        return (len(self.samples) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        n = len(self.samples)
+        order = torch.randperm(n).numpy() if self.shuffle else np.arange(n)
+        for s in range(0, n, self.batch_size):
+            idx = order[s:s + self.batch_size]
+            yield self.samples[idx], self.labels[idx]
+
+
+class EarlyStopper:
+    """torch_trainer.py:1098-1113."""
+
+    def __init__(self, patience=1, min_delta=0):
+        self.patience, self.min_delta = patience, min_delta
+        self.counter, self.min_validation_loss = 0, np.inf
+
+    def early_stop(self, validation_loss):
+        if validation_loss < self.min_validation_loss:
+            self.min_validation_loss = validation_loss
+            self.counter = 0
+        elif validation_loss > (self.min_validation_loss + self.min_delta):
+            self.counter += 1
+            if self.counter >= self.patience:
+                return True
+        return False
+
+
+class ReduceLROnPlateau:
+    """torch.optim.lr_scheduler.ReduceLROnPlateau('min', patience, eps=1e-7) as configured at
+    torch_trainer.py:63-66 (factor 0.1, rel threshold 1e-4, no cooldown, min_lr 0)."""
+
+    def __init__(self, lr, patience=10, factor=0.1, threshold=1e-4, eps=1e-7, min_lr=0.0):
+        self.lr, self.patience, self.factor, self.threshold, self.eps, self.min_lr = lr, patience, factor, threshold, eps, min_lr
+        self.best, self.num_bad_epochs = float("inf"), 0
+
+    def step(self, metric):
+        metric = float(metric)
+        if metric < self.best * (1.0 - self.threshold):
+            self.best, self.num_bad_epochs = metric, 0
+        else:
+            self.num_bad_epochs += 1
+        if self.num_bad_epochs > self.patience:
+            new_lr = max(self.lr * self.factor, self.min_lr)
+            if self.lr - new_lr > self.eps:
+                self.lr = new_lr
+            self.num_bad_epochs = 0
+        return self.lr
+
+
+class TrainEngine:
+    """Flat device buffers (parameters, gradients, Adam moments, BN running stats) of one
+    ``CamALResNet`` + the ``camal_trainer`` workspace."""
+
+    BETAS, EPS, BN_MOMENTUM = (0.9, 0.999), 1e-8, 0.1  # torch defaults (AdamW, BatchNorm1d)
+
+    def __init__(self, model, device, max_batch, length):
+        self.lib = _lib.load()
+        d = torch.device(device)
+        if d.type != "cuda":
+            raise _lib.CamalHipError(f"camal_amd trains on MI355X only (device={device!r}); there is no CPU path.")
+        self.device = torch.device("cuda", d.index if d.index is not None else torch.cuda.current_device())
+        if (model.in_channels, model.mid_channels, model.nb_class) != (1, 64, 2):
+            raise NotImplementedError("the HIP training path implements in_channels=1, mid_channels=64, nb_class=2")
+        self.k = model.kernel_size
+        self.keys = weights.trainable_keys(self.k)
+        self.bn_prefixes = [k[:-len(".running_mean")] for k in model._params if k.endswith("running_mean")]
+        self.n = int(self.lib.camal_trainer_param_count(self.k))
+        assert self.n == sum(model._params[k].size for k in self.keys)
+        self.n_running = int(self.lib.camal_trainer_running_count())
+        h = C.c_void_p()
+        _lib.check(self.lib.camal_trainer_create(self.device.index, self.k, int(max_batch), int(length), C.byref(h)))
+        self._h = h
+        self.max_batch, self.length = int(max_batch), int(length)
+        with torch.cuda.device(self.device):
+            self.params = torch.empty(self.n, dtype=torch.float32, device=self.device)
+            self.grads = torch.zeros_like(self.params)
+            self.m = torch.zeros_like(self.params)
+            self.v = torch.zeros_like(self.params)
+            self.running = torch.empty(self.n_running, dtype=torch.float32, device=self.device)
+            self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+            self.ncorrect = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.step_count = 0
+        self.load_from_model(model)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.camal_trainer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- model <-> flat buffers ------------------------------------------------------------
+    def load_from_model(self, model):
+        flat = np.concatenate([np.asarray(model._params[k], np.float32).ravel() for k in self.keys])
+        run = np.concatenate([np.concatenate([model._params[p + ".running_mean"].ravel(),
+                                              model._params[p + ".running_var"].ravel()]) for p in self.bn_prefixes])
+        self.params.copy_(torch.from_numpy(flat))
+        self.running.copy_(torch.from_numpy(run.astype(np.float32)))
+        self.num_batches_tracked = int(model._params[self.bn_prefixes[0] + ".num_batches_tracked"])
+
+    def store_to_model(self, model):
+        flat = self.params.cpu().numpy()
+        run = self.running.cpu().numpy()
+        o = 0
+        for k in self.keys:
+            n = model._params[k].size
+            model._params[k] = flat[o:o + n].reshape(model._params[k].shape).copy()
+            o += n
+        o = 0
+        for p in self.bn_prefixes:
+            c = model._params[p + ".running_mean"].size
+            model._params[p + ".running_mean"] = run[o:o + c].copy()
+            model._params[p + ".running_var"] = run[o + c:o + 2 * c].copy()
+            model._params[p + ".num_batches_tracked"] = np.array(self.num_batches_tracked, np.int64)
+            o += 2 * c
+        model._drop_engine()
+
+    # ---- one batch ----------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _prep(self, ts, labels):
+        x = torch.as_tensor(np.ascontiguousarray(np.asarray(ts, dtype=np.float32))) if not torch.is_tensor(ts) else ts.float()
+        if x.dim() == 3:
+            x = x[:, 0, :]
+        x = x.to(self.device).contiguous()
+        y = None
+        if labels is not None:
+            y = torch.as_tensor(np.asarray(labels)).to(self.device).float().long().to(torch.int32).contiguous()
+        return x, y
+
+    def forward_backward(self, ts, labels, update_running=True):
+        """Train-mode forward + backward; fills ``self.grads``.  -> (loss tensor[1], ncorrect tensor[1])"""
+        x, y = self._prep(ts, labels)
+        B, L = x.shape
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.camal_train_fwd_bwd(
+                self._h, _lib.ptr(self.params), _lib.ptr(self.running) if update_running else None, _lib.ptr(x),
+                _lib.ptr(y), B, L, self.BN_MOMENTUM, _lib.ptr(self.grads), None, _lib.ptr(self.loss),
+                _lib.ptr(self.ncorrect), self._stream()))
+        if update_running:
+            self.num_batches_tracked += 1
+        return self.loss, self.ncorrect
+
+    def forward_train(self, ts):
+        """Train-mode logits (batch statistics), no backward, running stats untouched."""
+        x, _ = self._prep(ts, None)
+        B, L = x.shape
+        with torch.cuda.device(self.device):
+            logits = torch.empty((B, 2), dtype=torch.float32, device=self.device)
+            _lib.check(self.lib.camal_train_fwd_bwd(self._h, _lib.ptr(self.params), None, _lib.ptr(x), None, B, L,
+                                                    self.BN_MOMENTUM, None, _lib.ptr(logits), None, None, self._stream()))
+        return logits
+
+    def optimizer_step(self, lr, weight_decay):
+        parallel.allreduce_mean_(self.grads)  # no-op unless torch.distributed is initialised
+        self.step_count += 1
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.camal_adamw_step(_lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.m),
+                                                 _lib.ptr(self.v), self.n, self.step_count, float(lr), self.BETAS[0],
+                                                 self.BETAS[1], self.EPS, float(weight_decay), self._stream()))
+
+    def optimizer_state_dict(self, lr, weight_decay):
+        return {"state": {"step": self.step_count, "exp_avg": self.m.cpu(), "exp_avg_sq": self.v.cpu(),
+                          "param_order": list(self.keys)},
+                "param_groups": [{"lr": lr, "betas": self.BETAS, "eps": self.EPS, "weight_decay": weight_decay}]}
+
+
+def forward_train(model, x):
+    """``CamALResNet.forward`` in train() mode outside a trainer: batch-statistics logits."""
+    xs = np.asarray(x.cpu() if torch.is_tensor(x) else x, dtype=np.float32)
+    if xs.ndim == 3:
+        xs = xs[:, 0, :]
+    eng = TrainEngine(model, model.device, xs.shape[0], xs.shape[1])
+    try:
+        return eng.forward_train(xs)
+    finally:
+        eng.close()
+
+
+class BasedClassifTrainer(object):
+    def __init__(self, model, train_loader, valid_loader=None, learning_rate=1e-3, weight_decay=1e-2,
+                 criterion=None, patience_es=None, patience_rlr=None, device="cuda", all_gpu=False,
+                 valid_criterion=None, n_warmup_epochs=0, f_metrics=Classifmetrics(), verbose=False,
+                 plotloss=False, save_fig=False, path_fig=None, save_checkpoint=False, path_checkpoint=None):
+        if criterion is not None or valid_criterion is not None:
+            raise NotImplementedError("the HIP training step implements nn.CrossEntropyLoss() (the reference default)")
+        self.model = model
+        self.train_loader, self.valid_loader = train_loader, valid_loader
+        self.f_metrics, self.device, self.all_gpu = f_metrics, device, all_gpu
+        self.verbose, self.plotloss = verbose, plotloss
+        self.save_checkpoint, self.save_fig, self.path_fig = save_checkpoint, save_fig, path_fig
+        self.path_checkpoint = path_checkpoint if path_checkpoint is not None else os.getcwd() + os.sep + "model"
+        self.patience_rlr, self.patience_es, self.n_warmup_epochs = patience_rlr, patience_es, n_warmup_epochs
+        self.lr, self.weight_decay = learning_rate, weight_decay
+        self.scheduler = ReduceLROnPlateau(learning_rate, patience=patience_rlr, eps=1e-7) if patience_rlr is not None else None
+
+        self.log = {}
+        self.train_time = self.eval_time = self.voter_time = 0
+        self.passed_epochs = 0
+        self.best_loss = np.inf
+        self.loss_train_history, self.loss_valid_history = [], []
+        self.accuracy_train_history, self.accuracy_valid_history = [], []
+        if self.patience_es is not None:
+            self.early_stopping = EarlyStopper(patience=self.patience_es)
+
+        self.model.to(self.device)
+        length = train_loader.samples.shape[-1]
+        self.engine = TrainEngine(self.model, self.device, train_loader.batch_size, length)
+
+    # ------------------------------------------------------------- train (torch_trainer.py:92-171)
+    def train(self, n_epochs=10):
+        tmp_time = time.time()
+        for epoch in range(n_epochs):
+            train_loss, train_accuracy = self.__train()
+            self.loss_train_history.append(train_loss)
+            self.accuracy_train_history.append(train_accuracy)
+            if self.valid_loader is not None:
+                valid_loss, valid_accuracy = self.__evaluate()
+                self.loss_valid_history.append(valid_loss)
+                self.accuracy_valid_history.append(valid_accuracy)
+            else:
+                valid_loss = train_loss
+
+            if self.scheduler:
+                self.lr = self.scheduler.step(valid_loss)
+
+            if self.patience_es is not None:
+                if self.passed_epochs > self.n_warmup_epochs:
+                    if self.early_stopping.early_stop(valid_loss):
+                        self.passed_epochs += 1
+                        if self.verbose:
+                            print("Early stopping after {} epochs !".format(epoch + 1))
+                        break
+
+            if self.verbose:
+                print("Epoch [{}/{}]".format(epoch + 1, n_epochs))
+                print("    Train loss : {:.4f}, Train acc : {:.2f}%".format(train_loss, train_accuracy * 100))
+                if self.valid_loader is not None:
+                    print("    Valid  loss : {:.4f}, Valid  acc : {:.2f}%".format(valid_loss, valid_accuracy * 100))
+
+            if valid_loss <= self.best_loss and self.passed_epochs >= self.n_warmup_epochs:
+                self.best_loss = valid_loss
+                self.engine.store_to_model(self.model)
+                self.log = {
+                    "valid_metrics": valid_accuracy if self.valid_loader is not None else train_accuracy,
+                    # a copy: the reference stores state_dict() by reference (:141), so its "best" weights
+                    # silently follow later epochs; the intent (restore_best_weights) needs a snapshot
+                    "best_model_state_dict": self.model.state_dict(),
+                    "optimizer_state_dict": self.engine.optimizer_state_dict(self.lr, self.weight_decay),
+                    "loss_train_history": self.loss_train_history,
+                    "loss_valid_history": self.loss_valid_history,
+                    "accuracy_train_history": self.accuracy_train_history,
+                    "accuracy_valid_history": self.accuracy_valid_history,
+                    "value_best_loss": self.best_loss,
+                    "epoch_best_loss": self.passed_epochs,
+                    "time_best_loss": round((time.time() - tmp_time), 3),
+                }
+                if self.save_checkpoint:
+                    self.save()
+            self.passed_epochs += 1
+
+        self.train_time = round((time.time() - tmp_time), 3)
+        self.engine.store_to_model(self.model)
+        self.log["training_time"] = self.train_time
+        self.log["loss_train_history"] = self.loss_train_history
+        self.log["loss_valid_history"] = self.loss_valid_history
+        self.log["accuracy_train_history"] = self.accuracy_train_history
+        self.log["accuracy_valid_history"] = self.accuracy_valid_history
+        if self.save_checkpoint:
+            self.save()
+        return
+
+    # ---------------------------------------------------------- evaluate (torch_trainer.py:173-207)
+    def evaluate(self, test_loader, mask="test_metrics", return_output=False):
+        tmp_time = time.time()
+        losses, y, y_hat = self._eval_loader(test_loader)
+        metrics = self.f_metrics(y, y_hat)
+        self.eval_time = round((time.time() - tmp_time), 3)
+        self.log[mask + "_time"] = self.eval_time
+        self.log[mask] = metrics
+        if self.save_checkpoint:
+            self.save()
+        if return_output:
+            return np.mean(losses), metrics, y, y_hat
+        return np.mean(losses), metrics
+
+    def save(self):
+        torch.save(self.log, self.path_checkpoint + ".pt")
+
+    def restore_best_weights(self):
+        try:
+            self.model.load_state_dict(self.log["best_model_state_dict"])
+            self.engine.load_from_model(self.model)
+        except KeyError:
+            warnings.warn("Error during loading log checkpoint state dict : no update.")
+        return
+
+    # ------------------------------------------------------------ private loops (:273-325)
+    def __train(self):
+        total, losses, corrects = 0, [], []
+        for ts, labels in self.train_loader:
+            loss, ncorrect = self.engine.forward_backward(ts, labels)
+            self.engine.optimizer_step(self.lr, self.weight_decay)
+            total += len(labels)
+            losses.append(loss.item())        # the reference syncs per batch too (:296-297)
+            corrects.append(ncorrect.item())
+        return np.mean(losses), np.sum(corrects) / total
+
+    def __evaluate(self):
+        losses, y, y_hat = self._eval_loader(self.valid_loader)
+        return np.mean(losses), float(np.sum(y == y_hat)) / len(y)
+
+    def _eval_loader(self, loader):
+        """eval()-mode forward of the whole loader through the BN-folded inference kernels.  The
+        reference iterates batch-1 loaders (core.py:114-119); per-sample eval-mode logits do not
+        depend on the batch they were computed in, so the per-batch losses are rebuilt from them."""
+        self.engine.store_to_model(self.model)
+        self.model.eval()
+        X = loader.samples[:, 0, :]
+        logits = self.model(X.astype(np.float32))
+        labels = torch.as_tensor(loader.labels).to(logits.device).float().long()
+        per_sample = torch.nn.functional.cross_entropy(logits.float(), labels, reduction="none")
+        n, bs = len(labels), loader.batch_size
+        losses = [per_sample[s:s + bs].mean().item() for s in range(0, n, bs)] if bs > 1 else per_sample.cpu().numpy().tolist()
+        y_hat = torch.max(logits, 1)[1].cpu().numpy()
+        self.model.train()
+        return losses, loader.labels.astype(np.float32), y_hat

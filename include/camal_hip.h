@@ -118,6 +118,46 @@ int camal_postprocess(int n_members, const float* cam_dev, const float* logits_d
 int camal_attention(const double* soft_dev, const double* x_dev, int B, int L, int w_ma,
                     double* state_out, void* stream);
 
+/* ------------------------------- training (one ResNet member) -------------------------------
+ * Replaces the per-batch body of BasedClassifTrainer.__train (torch_trainer.py:281-298) for
+ * CamALResNet in train() mode: forward with BatchNorm batch statistics (biased variance,
+ * running statistics updated with momentum and the unbiased variance), mean cross-entropy,
+ * backward, AdamW.  Parameters, gradients, optimizer moments and BN running statistics are
+ * flat fp32 DEVICE buffers owned by the caller (torch tensors), so that the data-parallel
+ * gradient all-reduce is one torch.distributed call on the gradient bucket between
+ * camal_train_fwd_bwd and camal_adamw_step (replaces nn.DataParallel, torch_trainer.py:82-90).
+ *
+ * Flat parameter order = CamALResNet.parameters() order (camal_resnet.py:13-19,35-54): for each
+ * block: 3 x (conv.weight [Cout][Cin][k], conv.bias, bn.weight, bn.bias), then the residual's
+ * (conv.weight [Cout][Cin][1], conv.bias, bn.weight, bn.bias) for blocks 1 and 2; finally
+ * linear.weight [2][128], linear.bias [2].  Running-statistics order: per BatchNorm in the same
+ * order, running_mean [C] then running_var [C].                                              */
+typedef struct camal_trainer camal_trainer;
+size_t camal_trainer_param_count(int kernel_size);   /* number of trainable floats P(k)        */
+size_t camal_trainer_running_count(void);            /* floats of BN running statistics        */
+int camal_trainer_create(int device_id, int kernel_size, int max_batch, int max_len, camal_trainer** out);
+int camal_trainer_destroy(camal_trainer* t);
+
+/* One forward(+backward) pass on a batch.
+ *   params_dev      flat parameters (read)
+ *   bn_running_dev  flat running statistics, updated in place (NULL: not updated)
+ *   x_dev [B][L] float32, y_dev [B] int32 labels (may be NULL when grads_dev is NULL)
+ *   bn_momentum     0.1 in the reference (torch default)
+ *   grads_dev       flat gradients of the MEAN cross-entropy, overwritten (NULL: forward only)
+ *   logits_dev      [B][2] out or NULL; loss_dev: 1 float out; ncorrect_dev: 1 int out
+ * Conv biases feed a train-mode BatchNorm, so their exact gradient is 0 and is written as 0
+ * (torch produces rounding noise there).                                                      */
+int camal_train_fwd_bwd(camal_trainer* t, const float* params_dev, float* bn_running_dev,
+                        const float* x_dev, const int* y_dev, int B, int L, float bn_momentum,
+                        float* grads_dev, float* logits_dev, float* loss_dev, int* ncorrect_dev,
+                        void* stream);
+
+/* torch.optim.AdamW update of a flat buffer (torch_trainer.py:35,292): decoupled weight decay,
+ * bias-corrected moments; `step` counts from 1.                                                */
+int camal_adamw_step(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, size_t n,
+                     int step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                     void* stream);
+
 /* HIP-event timing of the kernels the last camal_forward_cam / camal_localize call enqueued
  * (enable with camal_set_profiling(ctx, 1); costs two events per launch).  After the stream
  * has been synchronised, camal_get_profile returns, per kernel class, the number of launches

@@ -1,0 +1,89 @@
+"""CPU restatement (PyTorch fp32 autograd) of one CamAL training step.
+
+TEST INFRASTRUCTURE ONLY (see oracle/camal_oracle.py's header).  The reference's training
+arithmetic is torch's own: ``CamALResNet`` in ``train()`` mode, ``nn.CrossEntropyLoss()``,
+``loss.backward()``, ``optim.AdamW.step()`` (src/helpers/torch_trainer.py:35,281-292).  This module
+restates the model as ``torch.nn.functional`` calls on leaf tensors keyed by the reference's
+state-dict names, so gradients / updates can be compared tensor by tensor with the HIP path.
+Pinned against the reference's own classes by tests/golden/train_*.npz
+(tests/golden/make_golden.py::train_case).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from camal_amd import weights
+
+
+class FunctionalResNet:
+    def __init__(self, sd):
+        sd = weights.to_numpy_state_dict(sd)
+        self.k = weights.kernel_size_of(sd)
+        self.keys = weights.trainable_keys(self.k)
+        self.p = {k: torch.tensor(np.array(sd[k]), dtype=torch.float32, requires_grad=k in self.keys)
+                  for k in sd if not k.endswith("num_batches_tracked")}
+        self.nbt = int(sd["layers.0.layers.0.layers.1.num_batches_tracked"])
+
+    def parameters(self):
+        return [self.p[k] for k in self.keys]
+
+    def _bn(self, z, prefix, training):
+        return F.batch_norm(z, self.p[prefix + ".running_mean"], self.p[prefix + ".running_var"],
+                            self.p[prefix + ".weight"], self.p[prefix + ".bias"], training=training,
+                            momentum=0.1, eps=1e-5)
+
+    def forward(self, x, training=True):
+        p = self.p
+        if x.dim() == 2:
+            x = x[:, None, :]
+        for b in range(3):
+            h = x
+            for i in range(3):
+                pre = f"layers.{b}.layers.{i}"
+                w = p[pre + ".layers.0.weight"]
+                k = w.shape[-1]
+                h = F.conv1d(F.pad(h, (k // 2, k // 2), mode="replicate"), w, p[pre + ".layers.0.bias"])
+                h = F.relu(self._bn(h, pre + ".layers.1", training))
+            if f"layers.{b}.residual.0.weight" in p:
+                r = F.conv1d(x, p[f"layers.{b}.residual.0.weight"], p[f"layers.{b}.residual.0.bias"])
+                h = h + self._bn(r, f"layers.{b}.residual.1", training)
+            x = h
+        return F.linear(x.mean(dim=-1), p["linear.weight"], p["linear.bias"])
+
+    def state_dict(self):
+        out = {k: v.detach().numpy().copy() for k, v in self.p.items()}
+        for k in list(out):
+            if k.endswith("running_mean"):
+                out[k[:-len("running_mean")] + "num_batches_tracked"] = np.array(self.nbt, np.int64)
+        return out
+
+
+def loss_and_grads(sd, x, y):
+    """One train-mode forward/backward -> (loss, ncorrect, {key: grad}, updated state dict)."""
+    m = FunctionalResNet(sd)
+    logits = m.forward(torch.as_tensor(np.asarray(x, np.float32)))
+    labels = torch.as_tensor(np.asarray(y)).float().long()
+    loss = F.cross_entropy(logits.float(), labels)
+    loss.backward()
+    m.nbt += 1
+    grads = {k: m.p[k].grad.numpy().copy() for k in m.keys}
+    ncorrect = int((torch.max(logits, 1)[1] == labels).sum())
+    return float(loss.detach()), ncorrect, grads, m.state_dict()
+
+
+def train_steps(sd, batches, lr=1e-3, weight_decay=0.0):
+    """AdamW over a list of (x, y) batches -> (losses, final state dict)."""
+    m = FunctionalResNet(sd)
+    opt = torch.optim.AdamW(m.parameters(), lr=lr, weight_decay=weight_decay)
+    losses = []
+    for x, y in batches:
+        opt.zero_grad()
+        logits = m.forward(torch.as_tensor(np.asarray(x, np.float32)))
+        loss = F.cross_entropy(logits.float(), torch.as_tensor(np.asarray(y)).float().long())
+        loss.backward()
+        opt.step()
+        m.nbt += 1
+        losses.append(float(loss.detach()))
+    return losses, m.state_dict()

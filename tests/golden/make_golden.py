@@ -141,7 +141,64 @@ def run_case(name, data, seed, gain, w_ma=5, gated=False, members=None):
           f"size={os.path.getsize(os.path.join(HERE, name + '.npz')) / 1024:.0f} KB")
 
 
+def train_case(name, k, seed, n, length, batch, epochs, lr=1e-3):
+    """Training fixtures from the reference's own classes: one backward pass of CamALResNet in
+    train() mode under nn.CrossEntropyLoss (torch_trainer.py:288-291), and `epochs` epochs of
+    BasedClassifTrainer.train (AdamW, torch_trainer.py:92-171,273-300) on an unshuffled loader."""
+    from src.helpers.torch_trainer import BasedClassifTrainer
+    from src.helpers.torch_dataset import TSDataset
+    x, y = synth.ideal_windows(n, length, seed=seed)
+    sd0 = weights.make_state_dict(k, seed=seed, head_gain=1.0)
+    keys = weights.trainable_keys(k)
+
+    # (1) one forward/backward on the first batch
+    m = CamALResNet(kernel_size=k)
+    m.load_state_dict(to_torch_sd(sd0))
+    m.train()
+    xb = torch.from_numpy(x[:batch, None, :]).float()
+    yb = torch.from_numpy(y[:batch]).float()
+    logits = m(xb)
+    loss = torch.nn.CrossEntropyLoss()(logits.float(), yb.long())
+    loss.backward()
+    grads = {kk: p.grad.numpy().copy() for kk, p in m.named_parameters()}
+    assert list(grads) == keys
+    small = [kk for kk in keys if grads[kk].size <= 2048 and not kk.endswith("layers.0.bias") and not kk.endswith("residual.0.bias")]
+    sd1 = {kk: v.numpy().copy() for kk, v in m.state_dict().items()}
+    run_keys = [kk for kk in sd1 if kk.endswith("running_mean") or kk.endswith("running_var")]
+    out = dict(
+        k=np.array(k), seed=np.array(seed), n=np.array(n), length=np.array(length), batch=np.array(batch),
+        epochs=np.array(epochs), lr=np.array(lr),
+        step1_loss=np.array(float(loss)), step1_logits=logits.detach().numpy(),
+        step1_grad_norms=np.array([np.linalg.norm(grads[kk].astype(np.float64)) for kk in keys]),
+        step1_small_grads=np.concatenate([grads[kk].ravel() for kk in small]),
+        step1_big_grad_slices=np.concatenate([grads[kk].ravel()[::97] for kk in keys if grads[kk].size > 2048]),
+        step1_running=np.concatenate([sd1[kk].ravel() for kk in run_keys]),
+    )
+
+    # (2) the reference trainer for a few epochs
+    m2 = CamALResNet(kernel_size=k)
+    m2.load_state_dict(to_torch_sd(sd0))
+    loader = torch.utils.data.DataLoader(TSDataset(x, y), batch_size=batch, shuffle=False)
+    tr = BasedClassifTrainer(m2, train_loader=loader, valid_loader=None, learning_rate=lr, weight_decay=0,
+                             patience_es=None, patience_rlr=None, device="cpu", all_gpu=False, n_warmup_epochs=0)
+    tr.train(epochs)
+    sd2 = {kk: v.numpy().copy() for kk, v in m2.state_dict().items()}
+    fn_keys = [kk for kk in keys if not kk.endswith("layers.0.bias") and not kk.endswith("residual.0.bias")]
+    out.update(
+        loss_train_history=np.array(tr.loss_train_history), accuracy_train_history=np.array(tr.accuracy_train_history),
+        final_param_norms=np.array([np.linalg.norm(sd2[kk].astype(np.float64)) for kk in fn_keys]),
+        final_param_delta_norms=np.array([np.linalg.norm((sd2[kk] - sd0[kk]).astype(np.float64)) for kk in fn_keys]),
+        final_linear_weight=sd2["linear.weight"], final_running=np.concatenate([sd2[kk].ravel() for kk in run_keys]),
+        final_eval_logits=m2.eval()(torch.from_numpy(x[:batch, None, :]).float()).detach().numpy(),
+    )
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: k={k} loss1={float(loss):.4f} hist={np.round(tr.loss_train_history, 4).tolist()} "
+          f"acc={np.round(tr.accuracy_train_history, 3).tolist()} size={os.path.getsize(os.path.join(HERE, name + '.npz')) / 1024:.0f} KB")
+
+
 def main():
+    train_case("train_k7_l96", k=7, seed=201, n=48, length=96, batch=16, epochs=2)
+    train_case("train_k25_l70", k=25, seed=202, n=24, length=70, batch=12, epochs=1)
     # 1. the BASELINE config-1 shape, shrunk: full ensemble, float32 data
     run_case("ensemble_l256", synth.ukdale_windows(12, 256, seed=11), seed=101, gain=2.0)
     # 2. float64 data (output dtype follows the input, quirk 9), ragged length (not a tile multiple)

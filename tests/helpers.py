@@ -37,3 +37,26 @@ def rel_err(a, b):
     num = np.abs(a - b).max(axis=-1)
     den = np.maximum(np.abs(b).max(axis=-1), 1e-12)
     return float((num / den).max())
+
+
+# ---- training fixtures (tests/golden/train_*.npz, make_golden.py::train_case) ----------------
+def train_case_inputs(case):
+    from camal_amd import synth
+    k, seed = int(case["k"]), int(case["seed"])
+    x, y = synth.ideal_windows(int(case["n"]), int(case["length"]), seed=seed)
+    sd0 = weights.make_state_dict(k, seed=seed, head_gain=1.0)
+    return k, x, y, sd0
+
+
+def is_bn_fed_bias(key):
+    """Conv biases that feed a train-mode BatchNorm: exact gradient 0, torch yields rounding noise."""
+    return key.endswith("layers.0.bias") or key.endswith("residual.0.bias")
+
+
+def pack_train_views(keys, grads):
+    """Same views of a gradient dict as the fixture stores."""
+    norms = np.array([np.linalg.norm(np.asarray(grads[k], np.float64)) for k in keys])
+    small = np.concatenate([np.asarray(grads[k]).ravel() for k in keys
+                            if np.asarray(grads[k]).size <= 2048 and not is_bn_fed_bias(k)])
+    big = np.concatenate([np.asarray(grads[k]).ravel()[::97] for k in keys if np.asarray(grads[k]).size > 2048])
+    return norms, small, big
