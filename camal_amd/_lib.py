@@ -32,6 +32,7 @@ SIGNATURES = {
     "camal_destroy": (_i, [_vp]),
     "camal_set_member_weights": (_i, [_vp, _i, C.POINTER(C.c_float), _sz]),
     "camal_set_chunk_windows": (_i, [_vp, _i]),
+    "camal_set_fused": (_i, [_vp, _i]),
     "camal_forward_cam": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "camal_localize": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "camal_postprocess": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _vp, _vp, _vp, _vp, _vp]),

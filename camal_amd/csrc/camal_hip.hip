@@ -83,6 +83,7 @@ struct camal_ctx {
     int device = 0, E = 0, precision = 0, chunk = 256, cam_row = 1;
     int num_cu = 256;
     size_t lds_per_cu = 160 * 1024;
+    int fused = 1;  // blocks 2 and 3 as fused-block kernels (block_kernel); 0: one conv_kernel per layer
     std::vector<Member> m;
     std::vector<void*> owned;  // device allocations freed in destroy
     // workspace
@@ -160,11 +161,39 @@ struct Workspace {
 
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
+template <typename DT> struct BlockNT;
+template <> struct BlockNT<float> { static constexpr int NT = 2; };
+template <> struct BlockNT<__bf16> { static constexpr int NT = 4; };
+
+// can this member's blocks 2/3 run fused (LDS budget depends on the first kernel size)?
+bool fused_fits(const camal_ctx* c, int k) {
+    if (c->precision == CAMAL_FP32) {
+        using G3 = BlockGeom<float, C2, BlockNT<float>::NT>;
+        using G2 = BlockGeom<float, C1, BlockNT<float>::NT>;
+        return 2 * (size_t)G3::buf_bytes(k, false) + G3::HEAD_BYTES <= c->lds_per_cu && 2 * (size_t)G2::buf_bytes(k, true) <= c->lds_per_cu;
+    }
+    using G3 = BlockGeom<__bf16, C2, BlockNT<__bf16>::NT>;
+    using G2 = BlockGeom<__bf16, C1, BlockNT<__bf16>::NT>;
+    return 2 * (size_t)G3::buf_bytes(k, false) + G3::HEAD_BYTES <= c->lds_per_cu && 2 * (size_t)G2::buf_bytes(k, true) <= c->lds_per_cu;
+}
+
+// timesteps per CAM-head tile (decides the layout of the pooled partial sums)
+int head_tile_len(const camal_ctx* c, bool fused) {
+    if (c->precision == CAMAL_FP32) return fused ? BlockGeom<float, C2, BlockNT<float>::NT>::T : Geom<float, C2, C2>::TN;
+    return fused ? BlockGeom<__bf16, C2, BlockNT<__bf16>::NT>::T : Geom<__bf16, C2, C2>::TN;
+}
+
+// upper bound over both paths (workspace sizing)
+int head_tiles(const camal_ctx* c, int L) {
+    const int a = head_tile_len(c, true), b = head_tile_len(c, false);
+    const int t = a < b ? a : b;
+    return (L + t - 1) / t;
+}
+
 size_t workspace_layout(const camal_ctx* c, int BC, int L, Workspace* w, char* base) {
     const size_t es = c->precision == CAMAL_FP32 ? 4 : 2;
     const size_t n64 = align_up((size_t)BC * L * C1 * es), n128 = align_up((size_t)BC * L * C2 * es);
-    const int head_tn = c->precision == CAMAL_FP32 ? Geom<float, C2, C2>::TN : Geom<__bf16, C2, C2>::TN;
-    const int ntiles = (L + head_tn - 1) / head_tn;
+    const int ntiles = head_tiles(c, L);
     size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += bytes; return (void*)p; };
     Workspace t;
@@ -248,6 +277,37 @@ int launch_conv(camal_ctx* c, hipStream_t s, const Layer& ly, const void* in, co
                                                               ly.ks >> 1, nullptr);
 }
 
+template <typename DT, int CIN, bool HAS_RES, bool HEAD>
+int launch_block(camal_ctx* c, hipStream_t s, const Layer& l1, const Layer& l2, const Layer& l3, const Layer* lr,
+                 const void* in, void* out, const float* wfc, float* cam, float* part, int BC, int L) {
+    constexpr int NTB = BlockNT<DT>::NT;
+    using G = BlockGeom<DT, CIN, NTB>;
+    auto kern = block_kernel<DT, CIN, NTB, HAS_RES, HEAD>;
+    const size_t lds = 2 * (size_t)G::buf_bytes(l1.ks, HAS_RES) + (HEAD ? G::HEAD_BYTES : 0);
+    if (lds > c->lds_per_cu) return fail(CAMAL_ERR_ARG, "kernel size too large for the fused block tile");
+    static size_t attr_set = 0;
+    if (lds > attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = lds;
+    }
+    BlockArgs a;
+    a.in = in; a.out = out;
+    a.w1 = (const uint4*)l1.wpack; a.w2 = (const uint4*)l2.wpack; a.w3 = (const uint4*)l3.wpack;
+    a.wr = lr ? (const uint4*)lr->wpack : nullptr;
+    a.b1 = l1.bias; a.b2 = l2.bias; a.b3 = l3.bias; a.br = lr ? lr->bias : nullptr;
+    a.wfc = wfc; a.cam = cam; a.part = part;
+    a.L = L; a.ks1 = l1.ks; a.cam_row = c->cam_row;
+    a.tiles_per_window = (L + G::T - 1) / G::T;
+    const long long total = (long long)a.tiles_per_window * BC;
+    if (total > 0x7fffffffLL) return fail(CAMAL_ERR_ARG, "too many tiles in one pass");
+    a.total_tiles = (int)total;
+    const int grid = (int)std::min<long long>(total, (long long)c->num_cu);
+    ProfScope ps(c, s, HEAD ? 2 : 1);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(576), lds, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // One member's conv stack on BC windows: x -> cam row 1 [BC][L] + pooled partials [BC][ntiles][2]
 template <typename DT>
 int run_member(camal_ctx* c, hipStream_t s, const Member& m, const float* x, int BC, int L, const Workspace& w,
@@ -262,6 +322,12 @@ int run_member(camal_ctx* c, hipStream_t s, const Member& m, const float* x, int
     // block 1: ConvBlock(7), ConvBlock(3) + residual (camal_resnet.py:35-38,56-58)
     if ((r = launch_conv<DT, C1, C1, true, false, false>(c, s, m.conv[0], w.a1, nullptr, w.b1, nullptr, nullptr, nullptr, BC, L))) return r;
     if ((r = launch_conv<DT, C1, C1, true, true, false>(c, s, m.conv[1], w.b1, w.r1, w.a1, nullptr, nullptr, nullptr, BC, L))) return r;
+    if (c->fused && fused_fits(c, m.k)) {
+        // blocks 2 and 3: one fused kernel each (three ConvBlocks through LDS)
+        if ((r = launch_block<DT, C1, true, false>(c, s, m.conv[2], m.conv[3], m.conv[4], &m.res2, w.a1, w.a2, nullptr, nullptr, nullptr, BC, L))) return r;
+        if ((r = launch_block<DT, C2, false, true>(c, s, m.conv[5], m.conv[6], m.conv[7], nullptr, w.a2, nullptr, m.wfc, cam, part, BC, L))) return r;
+        return 0;
+    }
     // block 2: residual BN(Conv1x1) first (no ReLU), then ConvBlock(k), (7), (3)+residual
     if ((r = launch_conv<DT, C1, C2, false, false, false>(c, s, m.res2, w.a1, nullptr, w.r2, nullptr, nullptr, nullptr, BC, L))) return r;
     if ((r = launch_conv<DT, C1, C2, true, false, false>(c, s, m.conv[2], w.a1, nullptr, w.a2, nullptr, nullptr, nullptr, BC, L))) return r;
@@ -280,7 +346,8 @@ int run_member_any(camal_ctx* c, hipStream_t s, const Member& m, const float* x,
                                        : run_member<__bf16>(c, s, m, x, BC, L, w, cam, part);
     if (r) return r;
     ProfScope ps(c, s, 4);
-    hipLaunchKernelGGL(logits_kernel, dim3((BC + 127) / 128), dim3(128), 0, s, part, m.bfc, logits, BC, w.ntiles, L);
+    const int tl = head_tile_len(c, c->fused && fused_fits(c, m.k));
+    hipLaunchKernelGGL(logits_kernel, dim3((BC + 127) / 128), dim3(128), 0, s, part, m.bfc, logits, BC, (L + tl - 1) / tl, L);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -338,6 +405,12 @@ int camal_destroy(camal_ctx* c) {
     if (c->ws) (void)hipFree(c->ws);
     for (hipEvent_t e : c->pool) (void)hipEventDestroy(e);
     delete c;
+    return 0;
+}
+
+int camal_set_fused(camal_ctx* c, int fused) {
+    if (!c) return fail(CAMAL_ERR_ARG, "null context");
+    c->fused = fused != 0;
     return 0;
 }
 

@@ -374,6 +374,356 @@ __global__ __launch_bounds__((NWC + 1) * 64) void conv_kernel(const DT* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Fused ResNetBlock: the three ConvBlocks of block 2 or block 3 (camal_resnet.py:26-59) in ONE
+// kernel, intermediate activations never leave LDS.
+//
+// 8 compute waves (wave = 32 out-channels x NT*32 columns; 4 channel tiles x 2 column halves)
+// + 1 loader wave, persistent over time tiles of N = 64*NT computed columns.  Every layer
+// computes all N columns at the same positions p = t0 - 4 + c; the columns a layer cannot know
+// (its halo) are garbage that shrinks inward by the layer's padding, so T = N - 8 columns are
+// valid after the (k,7,3) stack and tiles advance by T.  Two LDS buffers P, Q alternate roles:
+//     X(P) --conv k--> A1(Q) --conv 7--> A2(P) --conv 3--> epilogue     (next tile: X in Q)
+// and the loader prefetches the next tile's X into the buffer A1 just vacated while conv 3 runs.
+// Replicate padding is per layer: X rows are clamped by the loader; after
+// conv k / conv 7 the first / last tile of a window overwrites the rows just outside [0, L)
+// of A1 / A2 with the edge row (fix_edges) before the next layer reads them.
+//   HAS_RES (block 2): out = relu(conv3) + BN(Conv1x1(X)) — the loader re-stages the centre rows
+//     of X beside the prefetch; the 1x1 product is accumulated by MFMA on top of the already
+//     rectified accumulator, so no second accumulator is needed.
+//   HEAD (block 3): CAM head as in conv_kernel; the 128 x L feature map is never written.
+// ---------------------------------------------------------------------------------------
+template <typename DT, int CIN, int NT>
+__device__ __forceinline__ void mma_layer(const char* buf, int R0, int ks, const uint4* wp, f32x16 (&acc)[NT]) {
+    constexpr int RB = CIN * (int)sizeof(DT), CPR = RB / 16, NCP = CIN / Elem<DT>::K_PER_PAIR;
+    constexpr int AR = sizeof(DT) == 4 ? 2 : 4;
+    static_assert(NCP % AR == 0 && NCP % 2 == 0, "ring sizes must divide the chunk pairs per tap");
+    const int h = (threadIdx.x & 63) >> 5;
+    const int total = ks * NCP;
+    uint4 a[AR];
+    uint4 bq[2][NT];
+#pragma unroll
+    for (int d = 0; d < AR - 1; ++d) a[d] = wp[(size_t)(d < total ? d : total - 1) * 64];
+    {
+        const char* rowp = buf + R0 * RB;
+        const int col = (h ^ swz<CPR>(R0)) << 4;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bq[0][nt] = *reinterpret_cast<const uint4*>(rowp + nt * 32 * RB + col);
+    }
+#pragma unroll 1
+    for (int j = 0; j < ks; ++j) {
+        const int row = R0 + j, rown = R0 + (j + 1 < ks ? j + 1 : j);
+        const int s = swz<CPR>(row), sn = swz<CPR>(rown);
+        const char* rowp = buf + row * RB;
+        const char* rowpn = buf + rown * RB;
+#pragma unroll
+        for (int cp = 0; cp < NCP; ++cp) {
+            int idx = j * NCP + cp + (AR - 1);
+            idx = idx < total ? idx : total - 1;
+            a[(cp + AR - 1) % AR] = wp[(size_t)idx * 64];
+            {
+                const char* rp = cp + 1 < NCP ? rowp : rowpn;
+                const int col = cp + 1 < NCP ? ((2 * (cp + 1) + h) ^ s) << 4 : (h ^ sn) << 4;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    bq[(cp + 1) & 1][nt] = *reinterpret_cast<const uint4*>(rp + nt * 32 * RB + col);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) mma_chunk(a[cp % AR], bq[cp & 1][nt], acc[nt], DT());
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// relu(acc + bias) of this wave's 32-channel x NT*32-column tile -> 128-channel LDS rows (row = column + guard)
+template <typename DT, int NT>
+__device__ __forceinline__ void store_act_lds(char* dst, int row0, const f32x16 (&acc)[NT], const float (&bv)[4][4],
+                                              int mt, int h) {
+    constexpr int RB = 128 * (int)sizeof(DT), CPR = RB / 16;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int row = row0 + nt * 32;
+        const int s = swz<CPR>(row);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int boff = (32 * mt + 8 * g + 4 * h) * (int)sizeof(DT);
+            DT* p = reinterpret_cast<DT*>(dst + row * RB + (((boff >> 4) ^ s) << 4) + (boff & 15));
+            store4(p, fmaxf(acc[nt][4 * g + 0] + bv[g][0], 0.f), fmaxf(acc[nt][4 * g + 1] + bv[g][1], 0.f),
+                   fmaxf(acc[nt][4 * g + 2] + bv[g][2], 0.f), fmaxf(acc[nt][4 * g + 3] + bv[g][3], 0.f));
+        }
+    }
+}
+
+// rows just outside the window take the edge row's values (replicate padding of THIS layer's output)
+template <typename DT>
+__device__ __forceinline__ void fix_edges(char* buf, int guard, int g, int c_first, int c_last, bool lo, bool hi, int lane) {
+    constexpr int RB = 128 * (int)sizeof(DT), CPR = RB / 16;
+    if (lane < CPR) {
+        if (lo) {
+            const int src = c_first + guard;
+            const uint4 v = *reinterpret_cast<const uint4*>(buf + src * RB + ((lane ^ swz<CPR>(src)) << 4));
+            for (int d = 1; d <= g; ++d) {
+                const int dst = src - d;
+                if (dst >= 0) *reinterpret_cast<uint4*>(buf + dst * RB + ((lane ^ swz<CPR>(dst)) << 4)) = v;
+            }
+        }
+        if (hi) {
+            const int src = c_last + guard;
+            const uint4 v = *reinterpret_cast<const uint4*>(buf + src * RB + ((lane ^ swz<CPR>(src)) << 4));
+            for (int d = 1; d <= g; ++d) {
+                const int dst = src + d;
+                *reinterpret_cast<uint4*>(buf + dst * RB + ((lane ^ swz<CPR>(dst)) << 4)) = v;
+            }
+        }
+    }
+}
+
+struct BlockArgs {
+    const void* in;   // [B][L][CIN]
+    void* out;        // [B][L][128]   (block 2)
+    const uint4 *w1, *w2, *w3, *wr;
+    const float *b1, *b2, *b3, *br;
+    const float* wfc;  // [2][128]     (block 3)
+    float* cam;        // [B][L]
+    float* part;       // [B][tiles_per_window][2]
+    int L, ks1, cam_row, tiles_per_window, total_tiles;
+};
+
+template <typename DT, int CIN, int NT>
+struct BlockGeom {
+    static constexpr int ES = sizeof(DT);
+    static constexpr int N = 64 * NT;          // computed columns per tile
+    static constexpr int T = N - 8;            // valid columns per tile (halo 4 each side after convs 7 and 3)
+    static constexpr int RBI = CIN * ES;       // X row bytes
+    static constexpr int RBA = 128 * ES;       // A1 / A2 row bytes
+    static constexpr int HEAD_BYTES = (4 * N * 2 + 16) * 4;
+    __host__ __device__ static constexpr int x_bytes(int ks) { return (((N + ks - 1) * RBI) + 1023) & ~1023; }
+    __host__ __device__ static constexpr int xc_bytes() { return ((N * RBI) + 1023) & ~1023; }
+    // one buffer must hold X, or A1 (N + 6 rows), or [next X | centre rows of X] (HAS_RES)
+    __host__ __device__ static constexpr int buf_bytes(int ks, bool has_res) {
+        int b = x_bytes(ks) + (has_res ? xc_bytes() : 0);
+        const int a = (((N + 6) * RBA) + 1023) & ~1023;
+        return b > a ? b : a;
+    }
+};
+
+template <typename DT, int CIN, int NT, bool HAS_RES, bool HEAD>
+__global__ __launch_bounds__(576) void block_kernel(BlockArgs a) {
+    using G = BlockGeom<DT, CIN, NT>;
+    constexpr int N = G::N, T = G::T, RBI = G::RBI, CPRI = RBI / 16;
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int L = a.L, ks1 = a.ks1, pad1 = ks1 >> 1;
+    const int bufb = G::buf_bytes(ks1, HAS_RES);
+    const int xb = G::x_bytes(ks1);
+    float* red = reinterpret_cast<float*>(lds + 2 * bufb);
+    const int tpw = a.tiles_per_window;
+
+    if (wave == 8) {
+        // ------------------------------ loader wave ------------------------------------
+        // rows r of the X tile <-> positions t0 - 4 - pad1 + r, clamped into the window
+        auto stage = [&](int tile, char* buf, int row_shift, int bytes) {
+            const int b = tile / tpw, t0 = (tile - b * tpw) * T;
+            const char* inb = reinterpret_cast<const char*>(a.in) + (size_t)b * L * RBI;
+            const int pieces = bytes >> 10;
+            for (int pc = 0; pc < pieces; ++pc) {
+                const int q = pc * 64 + lane;
+                const int row = q / CPRI, c = (q % CPRI) ^ swz<CPRI>(row);
+                int p = t0 - 4 - pad1 + row_shift + row;
+                p = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
+                glds16(inb + (size_t)p * RBI + c * 16, buf + pc * 1024);
+            }
+        };
+        int tile = blockIdx.x;
+        if (tile < a.total_tiles) stage(tile, lds, 0, xb);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int it = 0; tile < a.total_tiles; ++it, tile += gridDim.x) {
+            const int b = tile / tpw, t0 = (tile - b * tpw) * T;
+            const bool lo = t0 == 0, hi = L - 1 - t0 + 4 < N;  // position L-1 sits among this tile's columns
+            char* Q = lds + ((it + 1) & 1) * bufb;
+            __syncthreads();                       // B1: A1 complete
+            if (lo || hi) __syncthreads();         // after fix_edges(A1)
+            __syncthreads();                       // B2: A2 complete, A1 dead -> Q is free
+            if (lo || hi) __syncthreads();         // after fix_edges(A2)
+            const int next = tile + gridDim.x;
+            if (HAS_RES) {
+                stage(tile, Q + xb, pad1, G::xc_bytes());   // centre rows of THIS tile's X (row = column)
+                if (next < a.total_tiles) {
+                    stage(next, Q, 0, xb);
+                    // counted wait: the centre rows were issued first and the prefetch is at least 32
+                    // pieces (N rows of >= 128 bytes), so <= 32 outstanding means the centre rows landed
+                    // while most of the prefetch stays in flight
+                    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __syncthreads();                   // BR: centre rows landed
+            } else if (next < a.total_tiles) {
+                stage(next, Q, 0, xb);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (HEAD) { __syncthreads(); __syncthreads(); }
+            __syncthreads();                       // END: next X landed
+        }
+        return;
+    }
+
+    // ---------------------------------- compute waves --------------------------------------
+    const int mt = wave & 3, ng = wave >> 2;
+    const int r = lane & 31, h = lane >> 5;
+    const int col0 = ng * NT * 32 + r;  // this lane's first column
+    constexpr int NCPI = CIN / Elem<DT>::K_PER_PAIR, NCPA = 128 / Elem<DT>::K_PER_PAIR;
+    const uint4* w1 = a.w1 + (size_t)mt * ks1 * NCPI * 64 + lane;
+    const uint4* w2 = a.w2 + (size_t)mt * 7 * NCPA * 64 + lane;
+    const uint4* w3 = a.w3 + (size_t)mt * 3 * NCPA * 64 + lane;
+    auto load_bias = [&](const float* bp, float (&bv)[4][4]) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) load4(bp + 32 * mt + 8 * g + 4 * h, bv[g]);
+    };
+
+    __syncthreads();  // first X landed
+    int it = 0;
+    for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x, ++it) {
+        char* P = lds + (it & 1) * bufb;         // X, later A2
+        char* Q = lds + ((it + 1) & 1) * bufb;   // A1, later [next X | X centre]
+        const int b = tile / tpw, tx = tile - b * tpw, t0 = tx * T;
+        const bool lo = t0 == 0, hi = L - 1 - t0 + 4 < N;  // position L-1 sits among this tile's columns
+        const int c_first = 4 - t0, c_last = L - 1 - t0 + 4;  // columns of positions 0 and L-1
+
+        f32x16 acc[NT];
+        // ---- ConvBlock(k): X(P) -> A1(Q), rows = column + 3
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+        mma_layer<DT, CIN, NT>(P, col0, ks1, w1, acc);
+        float bv[4][4];
+        load_bias(a.b1, bv);
+        store_act_lds<DT, NT>(Q, col0 + 3, acc, bv, mt, h);
+        __syncthreads();  // B1
+        if (lo || hi) {
+            if (wave == 0) fix_edges<DT>(Q, 3, 3, c_first, c_last, lo, hi, lane);
+            __syncthreads();
+        }
+        // ---- ConvBlock(7): A1(Q) -> A2(P), rows = column + 1
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+        mma_layer<DT, 128, NT>(Q, col0, 7, w2, acc);
+        load_bias(a.b2, bv);
+        store_act_lds<DT, NT>(P, col0 + 1, acc, bv, mt, h);
+        __syncthreads();  // B2
+        if (lo || hi) {
+            if (wave == 0) fix_edges<DT>(P, 1, 1, c_first, c_last, lo, hi, lane);
+            __syncthreads();
+        }
+        // ---- ConvBlock(3): A2(P) -> registers
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+        mma_layer<DT, 128, NT>(P, col0, 3, w3, acc);
+        load_bias(a.b3, bv);
+
+        if constexpr (!HEAD) {
+            // relu(conv3 + b3) in registers, then the 1x1 skip accumulates on top by MFMA
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[nt][4 * g + i] = fmaxf(acc[nt][4 * g + i] + bv[g][i], 0.f);
+            if constexpr (HAS_RES) {
+                __syncthreads();  // BR: centre rows of X landed in Q + xb
+                const uint4* wr = a.wr + (size_t)mt * NCPI * 64 + lane;
+                mma_layer<DT, CIN, NT>(Q + xb, col0, 1, wr, acc);
+            }
+            float brv[4][4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (HAS_RES) load4(a.br + 32 * mt + 8 * g + 4 * h, brv[g]);
+                else brv[g][0] = brv[g][1] = brv[g][2] = brv[g][3] = 0.f;
+            }
+            DT* outp = reinterpret_cast<DT*>(a.out);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int c = col0 + nt * 32;
+                const int p = t0 - 4 + c;
+                if (c >= 4 && c < 4 + T && p < L) {
+                    const size_t o = ((size_t)b * L + p) * 128 + 32 * mt + 4 * h;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        store4(outp + o + 8 * g, acc[nt][4 * g + 0] + brv[g][0], acc[nt][4 * g + 1] + brv[g][1],
+                               acc[nt][4 * g + 2] + brv[g][2], acc[nt][4 * g + 3] + brv[g][3]);
+                }
+            }
+        } else {
+            float w0[4][4], w1v[4][4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                load4(a.wfc + 32 * mt + 8 * g + 4 * h, w0[g]);
+                load4(a.wfc + 128 + 32 * mt + 8 * g + 4 * h, w1v[g]);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float c0 = 0.f, c1 = 0.f;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float f = fmaxf(acc[nt][4 * g + i] + bv[g][i], 0.f);
+                        c0 = fmaf(w0[g][i], f, c0);
+                        c1 = fmaf(w1v[g][i], f, c1);
+                    }
+                c0 += __shfl_xor(c0, 32);
+                c1 += __shfl_xor(c1, 32);
+                if (h == 0) {
+                    const int c = col0 + nt * 32;
+                    red[(mt * N + c) * 2 + 0] = c0;
+                    red[(mt * N + c) * 2 + 1] = c1;
+                }
+            }
+            __syncthreads();
+            float s0 = 0.f, s1 = 0.f;
+            for (int c = threadIdx.x; c < N; c += 512) {
+                float c0 = 0.f, c1 = 0.f;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    c0 += red[(m * N + c) * 2 + 0];
+                    c1 += red[(m * N + c) * 2 + 1];
+                }
+                const int p = t0 - 4 + c;
+                if (c >= 4 && c < 4 + T && p < L) {
+                    a.cam[(size_t)b * L + p] = a.cam_row ? c1 : c0;
+                    s0 += c0;
+                    s1 += c1;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                s0 += __shfl_xor(s0, o);
+                s1 += __shfl_xor(s1, o);
+            }
+            float* red2 = red + 4 * N * 2;
+            if (lane == 0) { red2[2 * wave] = s0; red2[2 * wave + 1] = s1; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < 8; ++wv) { p0 += red2[2 * wv]; p1 += red2[2 * wv + 1]; }
+                float* po = a.part + ((size_t)b * tpw + tx) * 2;
+                po[0] = p0;
+                po[1] = p1;
+            }
+        }
+        __syncthreads();  // END
+    }
+}
+
 // logits[b][k] = (sum over tiles of part[b][tile][k]) / L + b_fc[k]   (camal_resnet.py:23)
 __device__ __forceinline__ void member_logits(const float* part, int ntiles, int L, const float* bfc, float& l0,
                                               float& l1) {

@@ -87,6 +87,10 @@ class Ensemble:
         except Exception:
             pass
 
+    def set_fused(self, fused=True):
+        """True (default): fused-block kernels for blocks 2/3; False: one kernel per ConvBlock."""
+        _lib.check(self.lib.camal_set_fused(self._h, int(bool(fused))))
+
     def set_chunk_windows(self, n):
         _lib.check(self.lib.camal_set_chunk_windows(self._h, int(n)))
 

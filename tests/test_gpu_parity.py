@@ -135,3 +135,30 @@ def test_bf16_localize_vs_reference(torch_cuda, name):
     assert safe.sum() >= len(safe) // 2
     assert (state[safe] == c["states"][safe]).mean() >= STATE_AGREE_MIN
     ens.close()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("L", [5, 120, 121, 248, 249, 700])
+def test_fused_blocks_equal_per_layer_kernels(torch_cuda, precision, L):
+    """block_kernel (default) against one conv_kernel per ConvBlock on the same inputs, at lengths
+    around the fused tile sizes (120 valid columns fp32, 248 bf16) so that first/last-tile edge
+    fix-ups, single-tile windows and ragged last tiles are all hit."""
+    from camal_amd import synth, weights
+    from camal_amd.engine import Ensemble
+    sds = [weights.make_state_dict(k, seed=17, head_gain=3.0) for k in (5, 25)]
+    x = synth.ukdale_windows(5, max(L, 8), seed=100 + L)[:, :L]
+    a = Ensemble(sds, device="cuda:0", precision=precision)
+    b = Ensemble(sds, device="cuda:0", precision=precision)
+    b.set_fused(False)
+    la, ca = a.forward_cam(x)
+    lb, cb = b.forward_cam(x)
+    ca, cb, la, lb = ca.cpu().numpy(), cb.cpu().numpy(), la.cpu().numpy(), lb.cpu().numpy()
+    if precision == "fp32":
+        # same products, same k-order per element: CAM rows agree to rounding of the 4-way channel-tile sum
+        assert rel_err(ca, cb) < 1e-5
+        assert rel_err(la.reshape(-1, 2).T, lb.reshape(-1, 2).T) < 1e-5
+    else:
+        # bf16: the per-layer path rounds the block-2 skip to bf16 in HBM, the fused one keeps it in fp32
+        assert rel_err(ca, cb) < 3e-2
+    a.close()
+    b.close()
