@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcamal_hip.so")
+LIB_PATH = os.environ.get("CAMAL_HIP_LIB") or os.path.join(_HERE, "libcamal_hip.so")  # override: A/B builds
 
 FP32, BF16 = 0, 1
 PROF_CLASSES = ("stem", "conv", "conv_cam_head", "post", "other")

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -389,6 +390,10 @@ int camal_create(int device_id, int n_members, const int* kernel_sizes, int prec
     HIP_TRY(hipSetDevice(device_id));
     camal_ctx* c = new camal_ctx();
     c->device = device_id; c->E = n_members; c->precision = precision;
+    // fused blocks pay 8 halo columns per tile: a win where the per-layer path is bandwidth/latency
+    // bound (bf16), a 6 % loss of MFMA work where it is already MFMA-bound (fp32, 128-column tiles)
+    c->fused = precision == CAMAL_BF16;
+    if (const char* e = getenv("CAMAL_FUSED")) c->fused = atoi(e) != 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
     c->m.resize(n_members);

@@ -142,6 +142,55 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+// K loop of one conv layer for one wave: acc[nt] += sum over taps and chunk pairs of
+// A (weights, 32 out-channels, streamed from L2 in packed order through a register ring that keeps
+// AR-1 loads in flight) x B (activations read from the LDS tile at row R0 + tap + 32 nt, one chunk
+// pair ahead).  Software-pipelined by hand; ring slots are static after unrolling.
+template <typename DT, int CIN, int NT>
+__device__ __forceinline__ void mma_layer(const char* buf, int R0, int ks, const uint4* wp, f32x16 (&acc)[NT]) {
+    constexpr int RB = CIN * (int)sizeof(DT), CPR = RB / 16, NCP = CIN / Elem<DT>::K_PER_PAIR;
+    constexpr int AR = sizeof(DT) == 4 ? 2 : 4;
+    static_assert(NCP % AR == 0 && NCP % 2 == 0, "ring sizes must divide the chunk pairs per tap");
+    const int h = (threadIdx.x & 63) >> 5;
+    const int total = ks * NCP;
+    uint4 a[AR];
+    uint4 bq[2][NT];
+#pragma unroll
+    for (int d = 0; d < AR - 1; ++d) a[d] = wp[(size_t)(d < total ? d : total - 1) * 64];
+    {
+        const char* rowp = buf + R0 * RB;
+        const int col = (h ^ swz<CPR>(R0)) << 4;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bq[0][nt] = *reinterpret_cast<const uint4*>(rowp + nt * 32 * RB + col);
+    }
+#pragma unroll 1
+    for (int j = 0; j < ks; ++j) {
+        const int row = R0 + j, rown = R0 + (j + 1 < ks ? j + 1 : j);
+        const int s = swz<CPR>(row), sn = swz<CPR>(rown);
+        const char* rowp = buf + row * RB;
+        const char* rowpn = buf + rown * RB;
+#pragma unroll
+        for (int cp = 0; cp < NCP; ++cp) {
+            int idx = j * NCP + cp + (AR - 1);
+            idx = idx < total ? idx : total - 1;
+            a[(cp + AR - 1) % AR] = wp[(size_t)idx * 64];
+            const char* rp = cp + 1 < NCP ? rowp : rowpn;
+            const int col = cp + 1 < NCP ? ((2 * (cp + 1) + h) ^ s) << 4 : (h ^ sn) << 4;
+            // issue order pinned by hand: each LDS read of the NEXT step's fragment rides in the shadow of
+            // an MFMA of this step (an MFMA holds the issue port for 8 of its 32 cycles), instead of a
+            // separate load phase during which the matrix pipe idles.  hipcc left alone sinks every load
+            // to just before its use; sched_group_barrier made it drop the register double buffer.
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                bq[(cp + 1) & 1][nt] = *reinterpret_cast<const uint4*>(rp + nt * 32 * RB + col);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_chunk(a[cp % AR], bq[cp & 1][nt], acc[nt], DT());
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
 template <typename DT, int CIN, int COUT, int NT, int NWC>
 struct ConvGeom {
     static constexpr int ES = sizeof(DT);
@@ -217,7 +266,6 @@ __global__ __launch_bounds__((NWC + 1) * 64) void conv_kernel(const DT* __restri
     const int mt = wave % MT, ng = wave / MT;
     const int r = lane & 31, h = lane >> 5;
     const uint4* wp = wpack + (size_t)mt * ks * NCP * 64 + lane;
-    const int total = ks * NCP;
     const int R0 = ng * NT * 32 + r;
 
     float bv[4][4];
@@ -236,47 +284,7 @@ __global__ __launch_bounds__((NWC + 1) * 64) void conv_kernel(const DT* __restri
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
 
-        // ---- K loop: taps x chunk pairs, software-pipelined by hand.  A fragments (weights) stream
-        //      from L2 in packed order (one coalesced 1 KiB read per wave and chunk pair) through a
-        //      register ring that keeps AR-1 loads in flight; B fragments (activations) are read
-        //      from LDS one chunk pair ahead into the other half of bq[2][NT].  hipcc otherwise
-        //      sinks every load to just before its use (vmcnt(0) in front of each MFMA group), so
-        //      the issue order is pinned with sched_barrier.  Ring slots are static after unrolling.
-        constexpr int AR = sizeof(DT) == 4 ? 2 : 4;
-        static_assert(NCP % AR == 0 && NCP % 2 == 0, "ring sizes must divide the chunk pairs per tap");
-        uint4 a[AR];
-        uint4 bq[2][NT];
-#pragma unroll
-        for (int d = 0; d < AR - 1; ++d) a[d] = wp[(size_t)(d < total ? d : total - 1) * 64];
-        {
-            const char* rowp = buf + R0 * RB;
-            const int col = (h ^ swz<CPR>(R0)) << 4;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bq[0][nt] = *reinterpret_cast<const uint4*>(rowp + nt * 32 * RB + col);
-        }
-        for (int j = 0; j < ks; ++j) {
-            const int row = R0 + j, rown = R0 + (j + 1 < ks ? j + 1 : j);
-            const int s = swz<CPR>(row), sn = swz<CPR>(rown);
-            const char* rowp = buf + row * RB;
-            const char* rowpn = buf + rown * RB;
-#pragma unroll
-            for (int cp = 0; cp < NCP; ++cp) {
-                int idx = j * NCP + cp + (AR - 1);
-                idx = idx < total ? idx : total - 1;
-                a[(cp + AR - 1) % AR] = wp[(size_t)idx * 64];
-                {
-                    const char* rp = cp + 1 < NCP ? rowp : rowpn;
-                    const int col = cp + 1 < NCP ? ((2 * (cp + 1) + h) ^ s) << 4 : (h ^ sn) << 4;
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        bq[(cp + 1) & 1][nt] = *reinterpret_cast<const uint4*>(rp + nt * 32 * RB + col);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) mma_chunk(a[cp % AR], bq[cp & 1][nt], acc[nt], DT());
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+        mma_layer<DT, CIN, NT>(buf, R0, ks, wp, acc);
 
         // ---- epilogue.  acc[nt][reg]: column t = tile + r, row co = 32 mt + (reg&3) + 8 (reg>>2) + 4 h
         if constexpr (!HEAD) {
@@ -393,49 +401,6 @@ __global__ __launch_bounds__((NWC + 1) * 64) void conv_kernel(const DT* __restri
 //     rectified accumulator, so no second accumulator is needed.
 //   HEAD (block 3): CAM head as in conv_kernel; the 128 x L feature map is never written.
 // ---------------------------------------------------------------------------------------
-template <typename DT, int CIN, int NT>
-__device__ __forceinline__ void mma_layer(const char* buf, int R0, int ks, const uint4* wp, f32x16 (&acc)[NT]) {
-    constexpr int RB = CIN * (int)sizeof(DT), CPR = RB / 16, NCP = CIN / Elem<DT>::K_PER_PAIR;
-    constexpr int AR = sizeof(DT) == 4 ? 2 : 4;
-    static_assert(NCP % AR == 0 && NCP % 2 == 0, "ring sizes must divide the chunk pairs per tap");
-    const int h = (threadIdx.x & 63) >> 5;
-    const int total = ks * NCP;
-    uint4 a[AR];
-    uint4 bq[2][NT];
-#pragma unroll
-    for (int d = 0; d < AR - 1; ++d) a[d] = wp[(size_t)(d < total ? d : total - 1) * 64];
-    {
-        const char* rowp = buf + R0 * RB;
-        const int col = (h ^ swz<CPR>(R0)) << 4;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bq[0][nt] = *reinterpret_cast<const uint4*>(rowp + nt * 32 * RB + col);
-    }
-#pragma unroll 1
-    for (int j = 0; j < ks; ++j) {
-        const int row = R0 + j, rown = R0 + (j + 1 < ks ? j + 1 : j);
-        const int s = swz<CPR>(row), sn = swz<CPR>(rown);
-        const char* rowp = buf + row * RB;
-        const char* rowpn = buf + rown * RB;
-#pragma unroll
-        for (int cp = 0; cp < NCP; ++cp) {
-            int idx = j * NCP + cp + (AR - 1);
-            idx = idx < total ? idx : total - 1;
-            a[(cp + AR - 1) % AR] = wp[(size_t)idx * 64];
-            {
-                const char* rp = cp + 1 < NCP ? rowp : rowpn;
-                const int col = cp + 1 < NCP ? ((2 * (cp + 1) + h) ^ s) << 4 : (h ^ sn) << 4;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    bq[(cp + 1) & 1][nt] = *reinterpret_cast<const uint4*>(rp + nt * 32 * RB + col);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) mma_chunk(a[cp % AR], bq[cp & 1][nt], acc[nt], DT());
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
-
 // relu(acc + bias) of this wave's 32-channel x NT*32-column tile -> 128-channel LDS rows (row = column + guard)
 template <typename DT, int NT>
 __device__ __forceinline__ void store_act_lds(char* dst, int row0, const f32x16 (&acc)[NT], const float (&bv)[4][4],

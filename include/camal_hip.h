@@ -66,7 +66,7 @@ int camal_set_member_weights(camal_ctx* ctx, int member, const float* folded_hos
  * default 256).                                                                           */
 int camal_set_chunk_windows(camal_ctx* ctx, int windows);
 
-/* 1 (default): blocks 2 and 3 of every member run as fused-block kernels (three ConvBlocks per
+/* 1 (default for bf16; fp32 defaults to 0; env CAMAL_FUSED overrides): blocks 2 and 3 of every member run as fused-block kernels (three ConvBlocks per
  * launch, intermediates in LDS); 0: one kernel per ConvBlock.  Same arithmetic per element; the
  * pooled sums are taken over different tile sizes, so logits agree to fp32 rounding.          */
 int camal_set_fused(camal_ctx* ctx, int fused);

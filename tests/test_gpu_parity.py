@@ -149,6 +149,7 @@ def test_fused_blocks_equal_per_layer_kernels(torch_cuda, precision, L):
     x = synth.ukdale_windows(5, max(L, 8), seed=100 + L)[:, :L]
     a = Ensemble(sds, device="cuda:0", precision=precision)
     b = Ensemble(sds, device="cuda:0", precision=precision)
+    a.set_fused(True)
     b.set_fused(False)
     la, ca = a.forward_cam(x)
     lb, cb = b.forward_cam(x)
