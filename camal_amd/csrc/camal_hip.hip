@@ -47,18 +47,23 @@ size_t blob_floats(int k) {
     return n;
 }
 
-// Tile configuration per precision (see conv_kernel): fp32 runs 8 compute waves x 2 column
-// tiles (one workgroup per CU, two waves per SIMD); bf16 4 compute waves x 4 column tiles
-// (two workgroups per CU).
-template <typename DT> struct TileCfg;
-template <> struct TileCfg<float> { static constexpr int NWC = 8, NT = 2; };
-template <> struct TileCfg<__bf16> { static constexpr int NWC = 4, NT = 4; };
-// fp32 128 -> 64 (only the dgrad of block 2's first conv): 512-byte rows and 256-step tiles
-// would not fit two LDS buffers, so one column tile per wave.
-template <typename DT, int CIN, int COUT> struct TileNT { static constexpr int NT = TileCfg<DT>::NT; };
+// Tile configuration (see conv_kernel).  bf16: 4 compute waves x 4 column tiles, two workgroups per
+// CU.  fp32: 4 compute waves x 2 column tiles with two workgroups per CU whenever two double-buffered
+// tiles fit the 160 KiB of LDS (independent workgroups drift apart, so one's epilogue overlaps the
+// other's MFMAs), else 8 compute waves in one workgroup per CU.
+// fp32 128 -> 64 (only the dgrad of block 2's first conv): one column tile per wave.
+template <typename DT, int CIN, int COUT> struct TileNT { static constexpr int NT = sizeof(DT) == 4 ? 2 : 4; };
 template <> struct TileNT<float, 128, 64> { static constexpr int NT = 1; };
-template <typename DT, int CIN, int COUT>
-using Geom = ConvGeom<DT, CIN, COUT, TileNT<DT, CIN, COUT>::NT, TileCfg<DT>::NWC>;
+template <typename DT, int CIN, int COUT, int NWC>
+using GeomW = ConvGeom<DT, CIN, COUT, TileNT<DT, CIN, COUT>::NT, NWC>;
+
+// fp32: two 4-wave workgroups per CU if their tiles fit, else one 8-wave workgroup
+template <typename DT, int CIN, int COUT, bool HEAD>
+bool use_small_wg(size_t lds_per_cu, int ks) {
+    if (sizeof(DT) != 4) return true;
+    using G = GeomW<DT, CIN, COUT, 4>;
+    return 2 * (2 * (size_t)G::buf_bytes(ks) + (HEAD ? G::HEAD_BYTES : 0)) <= lds_per_cu;
+}
 
 struct Layer {
     int cin = 0, cout = 0, ks = 0;
@@ -180,8 +185,11 @@ bool fused_fits(const camal_ctx* c, int k) {
 
 // timesteps per CAM-head tile (decides the layout of the pooled partial sums)
 int head_tile_len(const camal_ctx* c, bool fused) {
-    if (c->precision == CAMAL_FP32) return fused ? BlockGeom<float, C2, BlockNT<float>::NT>::T : Geom<float, C2, C2>::TN;
-    return fused ? BlockGeom<__bf16, C2, BlockNT<__bf16>::NT>::T : Geom<__bf16, C2, C2>::TN;
+    // the per-layer CAM head is the k = 3 ConvBlock: its tile configuration follows use_small_wg
+    if (c->precision == CAMAL_FP32)
+        return fused ? BlockGeom<float, C2, BlockNT<float>::NT>::T
+                     : (use_small_wg<float, C2, C2, true>(c->lds_per_cu, 3) ? GeomW<float, C2, C2, 4>::TN : GeomW<float, C2, C2, 8>::TN);
+    return fused ? BlockGeom<__bf16, C2, BlockNT<__bf16>::NT>::T : GeomW<__bf16, C2, C2, 4>::TN;
 }
 
 // upper bound over both paths (workspace sizing)
@@ -244,12 +252,12 @@ struct ProfScope {
 // ---- launches -------------------------------------------------------------------------
 // L_out: output rows per window; input rows per window L_in, input row for (t, tap j) = t + j - in_off;
 // zero_row == nullptr: out-of-range rows replicate the edge (forward), else they read zeros (dgrad).
-template <typename DT, int CIN, int COUT, bool RELU, bool HAS_RES, bool HEAD>
-int launch_conv_ex(camal_ctx* c, int num_cu, size_t lds_per_cu, int cam_row, hipStream_t s, const void* wpack,
-                   const float* bias, int ks, const void* in, const void* res, void* out, const float* wfc, float* cam,
-                   float* part, int BC, int L_out, int L_in, int in_off, const void* zero_row) {
-    using G = Geom<DT, CIN, COUT>;
-    auto kern = conv_kernel<DT, CIN, COUT, G::TN / (32 * G::NG), TileCfg<DT>::NWC, RELU, HAS_RES, HEAD>;
+template <typename DT, int CIN, int COUT, int NWC, bool RELU, bool HAS_RES, bool HEAD>
+int launch_conv_w(camal_ctx* c, int num_cu, size_t lds_per_cu, int cam_row, hipStream_t s, const void* wpack,
+                  const float* bias, int ks, const void* in, const void* res, void* out, const float* wfc, float* cam,
+                  float* part, int BC, int L_out, int L_in, int in_off, const void* zero_row) {
+    using G = GeomW<DT, CIN, COUT, NWC>;
+    auto kern = conv_kernel<DT, CIN, COUT, G::TN / (32 * G::NG), NWC, RELU, HAS_RES, HEAD>;
     const size_t lds = 2 * (size_t)G::buf_bytes(ks) + (HEAD ? G::HEAD_BYTES : 0);
     if (lds > lds_per_cu) return fail(CAMAL_ERR_ARG, "kernel size too large for the LDS tile");
     static size_t attr_set = 0;  // per instantiation
@@ -268,6 +276,19 @@ int launch_conv_ex(camal_ctx* c, int num_cu, size_t lds_per_cu, int cam_row, hip
                        (const DT*)zero_row);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+template <typename DT, int CIN, int COUT, bool RELU, bool HAS_RES, bool HEAD>
+int launch_conv_ex(camal_ctx* c, int num_cu, size_t lds_per_cu, int cam_row, hipStream_t s, const void* wpack,
+                   const float* bias, int ks, const void* in, const void* res, void* out, const float* wfc, float* cam,
+                   float* part, int BC, int L_out, int L_in, int in_off, const void* zero_row) {
+    if (use_small_wg<DT, CIN, COUT, HEAD>(lds_per_cu, ks))
+        return launch_conv_w<DT, CIN, COUT, 4, RELU, HAS_RES, HEAD>(c, num_cu, lds_per_cu, cam_row, s, wpack, bias, ks, in, res,
+                                                                    out, wfc, cam, part, BC, L_out, L_in, in_off, zero_row);
+    if constexpr (sizeof(DT) == 4)
+        return launch_conv_w<DT, CIN, COUT, 8, RELU, HAS_RES, HEAD>(c, num_cu, lds_per_cu, cam_row, s, wpack, bias, ks, in, res,
+                                                                    out, wfc, cam, part, BC, L_out, L_in, in_off, zero_row);
+    return fail(CAMAL_ERR_ARG, "kernel size too large for the LDS tile");
 }
 
 template <typename DT, int CIN, int COUT, bool RELU, bool HAS_RES, bool HEAD>

@@ -180,12 +180,34 @@ __device__ __forceinline__ void mma_layer(const char* buf, int R0, int ks, const
             // an MFMA of this step (an MFMA holds the issue port for 8 of its 32 cycles), instead of a
             // separate load phase during which the matrix pipe idles.  hipcc left alone sinks every load
             // to just before its use; sched_group_barrier made it drop the register double buffer.
+            if constexpr (sizeof(DT) == 4) {
+                // fp32: 4 k-steps per chunk; consecutive MFMAs alternate accumulators (k-step major) so that
+                // no MFMA waits on the result of the one issued just before it
+                const float* af = reinterpret_cast<const float*>(&a[cp % AR]);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                bq[(cp + 1) & 1][nt] = *reinterpret_cast<const uint4*>(rp + nt * 32 * RB + col);
-                __builtin_amdgcn_sched_barrier(0);
-                mma_chunk(a[cp % AR], bq[cp & 1][nt], acc[nt], DT());
-                __builtin_amdgcn_sched_barrier(0);
+                for (int ks4 = 0; ks4 < 4; ++ks4) {
+                    if (ks4 < NT)
+                        bq[(cp + 1) & 1][ks4] = *reinterpret_cast<const uint4*>(rp + ks4 * 32 * RB + col);
+                    if (NT > 4 && ks4 == 3)
+#pragma unroll
+                        for (int nt = 4; nt < NT; ++nt)
+                            bq[(cp + 1) & 1][nt] = *reinterpret_cast<const uint4*>(rp + nt * 32 * RB + col);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float* bf = reinterpret_cast<const float*>(&bq[cp & 1][nt]);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks4], bf[ks4], acc[nt], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    bq[(cp + 1) & 1][nt] = *reinterpret_cast<const uint4*>(rp + nt * 32 * RB + col);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_chunk(a[cp % AR], bq[cp & 1][nt], acc[nt], DT());
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
     }
