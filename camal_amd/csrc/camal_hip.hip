@@ -171,33 +171,47 @@ template <typename DT> struct BlockNT;
 template <> struct BlockNT<float> { static constexpr int NT = 2; };
 template <> struct BlockNT<__bf16> { static constexpr int NT = 4; };
 
+// LDS bytes of one fused-block workgroup
+template <typename DT, int CIN, int NWC, bool HAS_RES, bool HEAD>
+size_t block_lds(int k) {
+    using G = BlockGeom<DT, CIN, BlockNT<DT>::NT, NWC>;
+    return 2 * (size_t)G::buf_bytes(k, HAS_RES) + (HEAD ? G::HEAD_BYTES : 0);
+}
+
+// One 8-wave workgroup per CU (256-column tiles in bf16, 128 in fp32).  Measured alternative: two
+// 4-wave workgroups with 128-column bf16 tiles (CAMAL_BLOCK_WAVES=4) — their barriers overlap, but
+// twice the halo columns and weight traffic cost more: 981 vs 1061 TFLOP/s on the bf16 ensemble.
+template <typename DT, int CIN, bool HAS_RES, bool HEAD>
+int block_nwc(size_t lds_per_cu, int k) {
+    static const int want = getenv("CAMAL_BLOCK_WAVES") ? atoi(getenv("CAMAL_BLOCK_WAVES")) : 8;
+    if (want == 4 && sizeof(DT) == 2 && 2 * block_lds<DT, CIN, 4, HAS_RES, HEAD>(k) <= lds_per_cu) return 4;
+    return block_lds<DT, CIN, 8, HAS_RES, HEAD>(k) <= lds_per_cu ? 8 : 0;
+}
+
 // can this member's blocks 2/3 run fused (LDS budget depends on the first kernel size)?
 bool fused_fits(const camal_ctx* c, int k) {
-    if (c->precision == CAMAL_FP32) {
-        using G3 = BlockGeom<float, C2, BlockNT<float>::NT>;
-        using G2 = BlockGeom<float, C1, BlockNT<float>::NT>;
-        return 2 * (size_t)G3::buf_bytes(k, false) + G3::HEAD_BYTES <= c->lds_per_cu && 2 * (size_t)G2::buf_bytes(k, true) <= c->lds_per_cu;
-    }
-    using G3 = BlockGeom<__bf16, C2, BlockNT<__bf16>::NT>;
-    using G2 = BlockGeom<__bf16, C1, BlockNT<__bf16>::NT>;
-    return 2 * (size_t)G3::buf_bytes(k, false) + G3::HEAD_BYTES <= c->lds_per_cu && 2 * (size_t)G2::buf_bytes(k, true) <= c->lds_per_cu;
+    if (c->precision == CAMAL_FP32)
+        return block_nwc<float, C2, false, true>(c->lds_per_cu, k) && block_nwc<float, C1, true, false>(c->lds_per_cu, k);
+    return block_nwc<__bf16, C2, false, true>(c->lds_per_cu, k) && block_nwc<__bf16, C1, true, false>(c->lds_per_cu, k);
+}
+
+template <typename DT>
+int fused_head_tile(size_t lds_per_cu, int k) {
+    return block_nwc<DT, C2, false, true>(lds_per_cu, k) == 4 ? BlockGeom<DT, C2, BlockNT<DT>::NT, 4>::T
+                                                              : BlockGeom<DT, C2, BlockNT<DT>::NT, 8>::T;
 }
 
 // timesteps per CAM-head tile (decides the layout of the pooled partial sums)
-int head_tile_len(const camal_ctx* c, bool fused) {
+int head_tile_len(const camal_ctx* c, bool fused, int k) {
     // the per-layer CAM head is the k = 3 ConvBlock: its tile configuration follows use_small_wg
     if (c->precision == CAMAL_FP32)
-        return fused ? BlockGeom<float, C2, BlockNT<float>::NT>::T
+        return fused ? fused_head_tile<float>(c->lds_per_cu, k)
                      : (use_small_wg<float, C2, C2, true>(c->lds_per_cu, 3) ? GeomW<float, C2, C2, 4>::TN : GeomW<float, C2, C2, 8>::TN);
-    return fused ? BlockGeom<__bf16, C2, BlockNT<__bf16>::NT>::T : GeomW<__bf16, C2, C2, 4>::TN;
+    return fused ? fused_head_tile<__bf16>(c->lds_per_cu, k) : GeomW<__bf16, C2, C2, 4>::TN;
 }
 
-// upper bound over both paths (workspace sizing)
-int head_tiles(const camal_ctx* c, int L) {
-    const int a = head_tile_len(c, true), b = head_tile_len(c, false);
-    const int t = a < b ? a : b;
-    return (L + t - 1) / t;
-}
+// upper bound over every path (workspace sizing): the smallest head tile is 56 timesteps
+int head_tiles(const camal_ctx*, int L) { return (L + 55) / 56; }
 
 size_t workspace_layout(const camal_ctx* c, int BC, int L, Workspace* w, char* base) {
     const size_t es = c->precision == CAMAL_FP32 ? 4 : 2;
@@ -299,14 +313,13 @@ int launch_conv(camal_ctx* c, hipStream_t s, const Layer& ly, const void* in, co
                                                               ly.ks >> 1, nullptr);
 }
 
-template <typename DT, int CIN, bool HAS_RES, bool HEAD>
-int launch_block(camal_ctx* c, hipStream_t s, const Layer& l1, const Layer& l2, const Layer& l3, const Layer* lr,
-                 const void* in, void* out, const float* wfc, float* cam, float* part, int BC, int L) {
+template <typename DT, int CIN, int NWC, bool HAS_RES, bool HEAD>
+int launch_block_w(camal_ctx* c, hipStream_t s, const Layer& l1, const Layer& l2, const Layer& l3, const Layer* lr,
+                   const void* in, void* out, const float* wfc, float* cam, float* part, int BC, int L) {
     constexpr int NTB = BlockNT<DT>::NT;
-    using G = BlockGeom<DT, CIN, NTB>;
-    auto kern = block_kernel<DT, CIN, NTB, HAS_RES, HEAD>;
-    const size_t lds = 2 * (size_t)G::buf_bytes(l1.ks, HAS_RES) + (HEAD ? G::HEAD_BYTES : 0);
-    if (lds > c->lds_per_cu) return fail(CAMAL_ERR_ARG, "kernel size too large for the fused block tile");
+    using G = BlockGeom<DT, CIN, NTB, NWC>;
+    auto kern = block_kernel<DT, CIN, NTB, NWC, HAS_RES, HEAD>;
+    const size_t lds = block_lds<DT, CIN, NWC, HAS_RES, HEAD>(l1.ks);
     static size_t attr_set = 0;
     if (lds > attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -323,11 +336,21 @@ int launch_block(camal_ctx* c, hipStream_t s, const Layer& l1, const Layer& l2, 
     const long long total = (long long)a.tiles_per_window * BC;
     if (total > 0x7fffffffLL) return fail(CAMAL_ERR_ARG, "too many tiles in one pass");
     a.total_tiles = (int)total;
-    const int grid = (int)std::min<long long>(total, (long long)c->num_cu);
+    const int per_cu = std::max(1, (int)(c->lds_per_cu / lds));
+    const int grid = (int)std::min<long long>(total, (long long)c->num_cu * per_cu);
     ProfScope ps(c, s, HEAD ? 2 : 1);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(576), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(G::THREADS), lds, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+template <typename DT, int CIN, bool HAS_RES, bool HEAD>
+int launch_block(camal_ctx* c, hipStream_t s, const Layer& l1, const Layer& l2, const Layer& l3, const Layer* lr,
+                 const void* in, void* out, const float* wfc, float* cam, float* part, int BC, int L) {
+    const int nwc = block_nwc<DT, CIN, HAS_RES, HEAD>(c->lds_per_cu, l1.ks);
+    if (nwc == 4) return launch_block_w<DT, CIN, 4, HAS_RES, HEAD>(c, s, l1, l2, l3, lr, in, out, wfc, cam, part, BC, L);
+    if (nwc == 8) return launch_block_w<DT, CIN, 8, HAS_RES, HEAD>(c, s, l1, l2, l3, lr, in, out, wfc, cam, part, BC, L);
+    return fail(CAMAL_ERR_ARG, "kernel size too large for the fused block tile");
 }
 
 // One member's conv stack on BC windows: x -> cam row 1 [BC][L] + pooled partials [BC][ntiles][2]
@@ -368,7 +391,7 @@ int run_member_any(camal_ctx* c, hipStream_t s, const Member& m, const float* x,
                                        : run_member<__bf16>(c, s, m, x, BC, L, w, cam, part);
     if (r) return r;
     ProfScope ps(c, s, 4);
-    const int tl = head_tile_len(c, c->fused && fused_fits(c, m.k));
+    const int tl = head_tile_len(c, c->fused && fused_fits(c, m.k), m.k);
     hipLaunchKernelGGL(logits_kernel, dim3((BC + 127) / 128), dim3(128), 0, s, part, m.bfc, logits, BC, (L + tl - 1) / tl, L);
     HIP_TRY(hipGetLastError());
     return 0;

@@ -408,8 +408,8 @@ __global__ __launch_bounds__((NWC + 1) * 64) void conv_kernel(const DT* __restri
 // Fused ResNetBlock: the three ConvBlocks of block 2 or block 3 (camal_resnet.py:26-59) in ONE
 // kernel, intermediate activations never leave LDS.
 //
-// 8 compute waves (wave = 32 out-channels x NT*32 columns; 4 channel tiles x 2 column halves)
-// + 1 loader wave, persistent over time tiles of N = 64*NT computed columns.  Every layer
+// NWC compute waves (wave = 32 out-channels x NT*32 columns; 4 channel tiles x NWC/4 column groups)
+// + 1 loader wave, persistent over time tiles of N = (NWC/4)*32*NT computed columns.  Every layer
 // computes all N columns at the same positions p = t0 - 4 + c; the columns a layer cannot know
 // (its halo) are garbage that shrinks inward by the layer's padding, so T = N - 8 columns are
 // valid after the (k,7,3) stack and tiles advance by T.  Two LDS buffers P, Q alternate roles:
@@ -477,14 +477,15 @@ struct BlockArgs {
     int L, ks1, cam_row, tiles_per_window, total_tiles;
 };
 
-template <typename DT, int CIN, int NT>
+template <typename DT, int CIN, int NT, int NWC>
 struct BlockGeom {
     static constexpr int ES = sizeof(DT);
-    static constexpr int N = 64 * NT;          // computed columns per tile
+    static constexpr int N = (NWC / 4) * 32 * NT;  // computed columns per tile
+    static constexpr int THREADS = (NWC + 1) * 64;
     static constexpr int T = N - 8;            // valid columns per tile (halo 4 each side after convs 7 and 3)
     static constexpr int RBI = CIN * ES;       // X row bytes
     static constexpr int RBA = 128 * ES;       // A1 / A2 row bytes
-    static constexpr int HEAD_BYTES = (4 * N * 2 + 16) * 4;
+    static constexpr int HEAD_BYTES = (4 * N * 2 + 2 * NWC) * 4;
     __host__ __device__ static constexpr int x_bytes(int ks) { return (((N + ks - 1) * RBI) + 1023) & ~1023; }
     __host__ __device__ static constexpr int xc_bytes() { return ((N * RBI) + 1023) & ~1023; }
     // one buffer must hold X, or A1 (N + 6 rows), or [next X | centre rows of X] (HAS_RES)
@@ -495,9 +496,9 @@ struct BlockGeom {
     }
 };
 
-template <typename DT, int CIN, int NT, bool HAS_RES, bool HEAD>
-__global__ __launch_bounds__(576) void block_kernel(BlockArgs a) {
-    using G = BlockGeom<DT, CIN, NT>;
+template <typename DT, int CIN, int NT, int NWC, bool HAS_RES, bool HEAD>
+__global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
+    using G = BlockGeom<DT, CIN, NT, NWC>;
     constexpr int N = G::N, T = G::T, RBI = G::RBI, CPRI = RBI / 16;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int lane = threadIdx.x & 63;
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(576) void block_kernel(BlockArgs a) {
     float* red = reinterpret_cast<float*>(lds + 2 * bufb);
     const int tpw = a.tiles_per_window;
 
-    if (wave == 8) {
+    if (wave == NWC) {
         // ------------------------------ loader wave ------------------------------------
         // rows r of the X tile <-> positions t0 - 4 - pad1 + r, clamped into the window
         auto stage = [&](int tile, char* buf, int row_shift, int bytes) {
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(576) void block_kernel(BlockArgs a) {
             }
             __syncthreads();
             float s0 = 0.f, s1 = 0.f;
-            for (int c = threadIdx.x; c < N; c += 512) {
+            for (int c = threadIdx.x; c < N; c += NWC * 64) {
                 float c0 = 0.f, c1 = 0.f;
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
@@ -701,7 +702,7 @@ __global__ __launch_bounds__(576) void block_kernel(BlockArgs a) {
             if (threadIdx.x == 0) {
                 float p0 = 0.f, p1 = 0.f;
 #pragma unroll
-                for (int wv = 0; wv < 8; ++wv) { p0 += red2[2 * wv]; p1 += red2[2 * wv + 1]; }
+                for (int wv = 0; wv < NWC; ++wv) { p0 += red2[2 * wv]; p1 += red2[2 * wv + 1]; }
                 float* po = a.part + ((size_t)b * tpw + tx) * 2;
                 po[0] = p0;
                 po[1] = p1;
