@@ -171,21 +171,25 @@ template <typename DT> struct BlockNT;
 template <> struct BlockNT<float> { static constexpr int NT = 2; };
 template <> struct BlockNT<__bf16> { static constexpr int NT = 4; };
 
+// out-channel tiles per wave: NWC = 8 -> 1 (wave = 32 channels), NWC = 4 -> 2 (wave = 64 channels,
+// one compute wave per SIMD with twice the MFMAs per operand load); the tile width N is the same.
+template <typename DT, int CIN, int NWC>
+using BGeom = BlockGeom<DT, CIN, BlockNT<DT>::NT, NWC, 8 / NWC>;
+
 // LDS bytes of one fused-block workgroup
 template <typename DT, int CIN, int NWC, bool HAS_RES, bool HEAD>
 size_t block_lds(int k) {
-    using G = BlockGeom<DT, CIN, BlockNT<DT>::NT, NWC>;
+    using G = BGeom<DT, CIN, NWC>;
     return 2 * (size_t)G::buf_bytes(k, HAS_RES) + (HEAD ? G::HEAD_BYTES : 0);
 }
 
-// One 8-wave workgroup per CU (256-column tiles in bf16, 128 in fp32).  Measured alternative: two
-// 4-wave workgroups with 128-column bf16 tiles (CAMAL_BLOCK_WAVES=4) — their barriers overlap, but
-// twice the halo columns and weight traffic cost more: 981 vs 1061 TFLOP/s on the bf16 ensemble.
+// One workgroup per CU, 256-column tiles in bf16 and 128 in fp32, as 8 compute waves (wave = 32
+// channels x half the columns) or 4 (wave = 64 channels x half the columns; CAMAL_BLOCK_WAVES).
 template <typename DT, int CIN, bool HAS_RES, bool HEAD>
 int block_nwc(size_t lds_per_cu, int k) {
     static const int want = getenv("CAMAL_BLOCK_WAVES") ? atoi(getenv("CAMAL_BLOCK_WAVES")) : 8;
-    if (want == 4 && sizeof(DT) == 2 && 2 * block_lds<DT, CIN, 4, HAS_RES, HEAD>(k) <= lds_per_cu) return 4;
-    return block_lds<DT, CIN, 8, HAS_RES, HEAD>(k) <= lds_per_cu ? 8 : 0;
+    if (block_lds<DT, CIN, 8, HAS_RES, HEAD>(k) > lds_per_cu) return 0;
+    return want == 4 ? 4 : 8;
 }
 
 // can this member's blocks 2/3 run fused (LDS budget depends on the first kernel size)?
@@ -197,8 +201,7 @@ bool fused_fits(const camal_ctx* c, int k) {
 
 template <typename DT>
 int fused_head_tile(size_t lds_per_cu, int k) {
-    return block_nwc<DT, C2, false, true>(lds_per_cu, k) == 4 ? BlockGeom<DT, C2, BlockNT<DT>::NT, 4>::T
-                                                              : BlockGeom<DT, C2, BlockNT<DT>::NT, 8>::T;
+    return BGeom<DT, C2, 8>::T;  // same tile width for both wave shapes
 }
 
 // timesteps per CAM-head tile (decides the layout of the pooled partial sums)
@@ -317,8 +320,8 @@ template <typename DT, int CIN, int NWC, bool HAS_RES, bool HEAD>
 int launch_block_w(camal_ctx* c, hipStream_t s, const Layer& l1, const Layer& l2, const Layer& l3, const Layer* lr,
                    const void* in, void* out, const float* wfc, float* cam, float* part, int BC, int L) {
     constexpr int NTB = BlockNT<DT>::NT;
-    using G = BlockGeom<DT, CIN, NTB, NWC>;
-    auto kern = block_kernel<DT, CIN, NTB, NWC, HAS_RES, HEAD>;
+    using G = BGeom<DT, CIN, NWC>;
+    auto kern = block_kernel<DT, CIN, NTB, NWC, 8 / NWC, HAS_RES, HEAD>;
     const size_t lds = block_lds<DT, CIN, NWC, HAS_RES, HEAD>(l1.ks);
     static size_t attr_set = 0;
     if (lds > attr_set) {

@@ -146,17 +146,21 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 // A (weights, 32 out-channels, streamed from L2 in packed order through a register ring that keeps
 // AR-1 loads in flight) x B (activations read from the LDS tile at row R0 + tap + 32 nt, one chunk
 // pair ahead).  Software-pipelined by hand; ring slots are static after unrolling.
-template <typename DT, int CIN, int NT>
-__device__ __forceinline__ void mma_layer(const char* buf, int R0, int ks, const uint4* wp, f32x16 (&acc)[NT]) {
+template <typename DT, int CIN, int NT, int MTW = 1>
+__device__ __forceinline__ void mma_layer(const char* buf, int R0, int ks, const uint4* wp, f32x16 (&acc)[MTW][NT]) {
+    // MTW = out-channel tiles per wave (consecutive in the packed weights: stride ks*NCP*64 uint4)
     constexpr int RB = CIN * (int)sizeof(DT), CPR = RB / 16, NCP = CIN / Elem<DT>::K_PER_PAIR;
     constexpr int AR = sizeof(DT) == 4 ? 2 : 4;
     static_assert(NCP % AR == 0 && NCP % 2 == 0, "ring sizes must divide the chunk pairs per tap");
     const int h = (threadIdx.x & 63) >> 5;
     const int total = ks * NCP;
-    uint4 a[AR];
+    const size_t mstride = (size_t)total * 64;
+    uint4 a[AR][MTW];
     uint4 bq[2][NT];
 #pragma unroll
-    for (int d = 0; d < AR - 1; ++d) a[d] = wp[(size_t)(d < total ? d : total - 1) * 64];
+    for (int d = 0; d < AR - 1; ++d)
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) a[d][m] = wp[m * mstride + (size_t)(d < total ? d : total - 1) * 64];
     {
         const char* rowp = buf + R0 * RB;
         const int col = (h ^ swz<CPR>(R0)) << 4;
@@ -173,17 +177,17 @@ __device__ __forceinline__ void mma_layer(const char* buf, int R0, int ks, const
         for (int cp = 0; cp < NCP; ++cp) {
             int idx = j * NCP + cp + (AR - 1);
             idx = idx < total ? idx : total - 1;
-            a[(cp + AR - 1) % AR] = wp[(size_t)idx * 64];
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) a[(cp + AR - 1) % AR][m] = wp[m * mstride + (size_t)idx * 64];
             const char* rp = cp + 1 < NCP ? rowp : rowpn;
             const int col = cp + 1 < NCP ? ((2 * (cp + 1) + h) ^ s) << 4 : (h ^ sn) << 4;
             // issue order pinned by hand: each LDS read of the NEXT step's fragment rides in the shadow of
-            // an MFMA of this step (an MFMA holds the issue port for 8 of its 32 cycles), instead of a
+            // the MFMAs of this step (an MFMA holds the issue port for 8 of its 32 cycles), instead of a
             // separate load phase during which the matrix pipe idles.  hipcc left alone sinks every load
             // to just before its use; sched_group_barrier made it drop the register double buffer.
             if constexpr (sizeof(DT) == 4) {
                 // fp32: 4 k-steps per chunk; consecutive MFMAs alternate accumulators (k-step major) so that
                 // no MFMA waits on the result of the one issued just before it
-                const float* af = reinterpret_cast<const float*>(&a[cp % AR]);
 #pragma unroll
                 for (int ks4 = 0; ks4 < 4; ++ks4) {
                     if (ks4 < NT)
@@ -196,7 +200,11 @@ __device__ __forceinline__ void mma_layer(const char* buf, int R0, int ks, const
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         const float* bf = reinterpret_cast<const float*>(&bq[cp & 1][nt]);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks4], bf[ks4], acc[nt], 0, 0, 0);
+#pragma unroll
+                        for (int m = 0; m < MTW; ++m) {
+                            const float* af = reinterpret_cast<const float*>(&a[cp % AR][m]);
+                            acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks4], bf[ks4], acc[m][nt], 0, 0, 0);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -205,7 +213,8 @@ __device__ __forceinline__ void mma_layer(const char* buf, int R0, int ks, const
                 for (int nt = 0; nt < NT; ++nt) {
                     bq[(cp + 1) & 1][nt] = *reinterpret_cast<const uint4*>(rp + nt * 32 * RB + col);
                     __builtin_amdgcn_sched_barrier(0);
-                    mma_chunk(a[cp % AR], bq[cp & 1][nt], acc[nt], DT());
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m) mma_chunk(a[cp % AR][m], bq[cp & 1][nt], acc[m][nt], DT());
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -300,13 +309,14 @@ __global__ __launch_bounds__((NWC + 1) * 64) void conv_kernel(const DT* __restri
         const char* buf = lds + (it & 1) * bufb;
         const int b = tile / tiles_per_window, tx = tile - b * tiles_per_window, t0 = tx * TN;
 
-        f32x16 acc[NT];
+        f32x16 accw[1][NT];
+        f32x16 (&acc)[NT] = accw[0];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
 
-        mma_layer<DT, CIN, NT>(buf, R0, ks, wp, acc);
+        mma_layer<DT, CIN, NT, 1>(buf, R0, ks, wp, accw);
 
         // ---- epilogue.  acc[nt][reg]: column t = tile + r, row co = 32 mt + (reg&3) + 8 (reg>>2) + 4 h
         if constexpr (!HEAD) {
@@ -477,10 +487,10 @@ struct BlockArgs {
     int L, ks1, cam_row, tiles_per_window, total_tiles;
 };
 
-template <typename DT, int CIN, int NT, int NWC>
+template <typename DT, int CIN, int NT, int NWC, int MTW = 1>
 struct BlockGeom {
     static constexpr int ES = sizeof(DT);
-    static constexpr int N = (NWC / 4) * 32 * NT;  // computed columns per tile
+    static constexpr int N = (NWC * MTW / 4) * 32 * NT;  // computed columns per tile
     static constexpr int THREADS = (NWC + 1) * 64;
     static constexpr int T = N - 8;            // valid columns per tile (halo 4 each side after convs 7 and 3)
     static constexpr int RBI = CIN * ES;       // X row bytes
@@ -496,9 +506,9 @@ struct BlockGeom {
     }
 };
 
-template <typename DT, int CIN, int NT, int NWC, bool HAS_RES, bool HEAD>
+template <typename DT, int CIN, int NT, int NWC, int MTW, bool HAS_RES, bool HEAD>
 __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
-    using G = BlockGeom<DT, CIN, NT, NWC>;
+    using G = BlockGeom<DT, CIN, NT, NWC, MTW>;
     constexpr int N = G::N, T = G::T, RBI = G::RBI, CPRI = RBI / 16;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int lane = threadIdx.x & 63;
@@ -560,16 +570,26 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
     }
 
     // ---------------------------------- compute waves --------------------------------------
-    const int mt = wave & 3, ng = wave >> 2;
+    // wave = MTW out-channel tiles (32 each) x NT column tiles; 4/MTW waves across channels
+    constexpr int WM = 4 / MTW;
+    const int mt0 = (wave % WM) * MTW, ng = wave / WM;
     const int r = lane & 31, h = lane >> 5;
     const int col0 = ng * NT * 32 + r;  // this lane's first column
     constexpr int NCPI = CIN / Elem<DT>::K_PER_PAIR, NCPA = 128 / Elem<DT>::K_PER_PAIR;
-    const uint4* w1 = a.w1 + (size_t)mt * ks1 * NCPI * 64 + lane;
-    const uint4* w2 = a.w2 + (size_t)mt * 7 * NCPA * 64 + lane;
-    const uint4* w3 = a.w3 + (size_t)mt * 3 * NCPA * 64 + lane;
-    auto load_bias = [&](const float* bp, float (&bv)[4][4]) {
+    const uint4* w1 = a.w1 + (size_t)mt0 * ks1 * NCPI * 64 + lane;
+    const uint4* w2 = a.w2 + (size_t)mt0 * 7 * NCPA * 64 + lane;
+    const uint4* w3 = a.w3 + (size_t)mt0 * 3 * NCPA * 64 + lane;
+    auto load_bias = [&](const float* bp, int mt, float (&bv)[4][4]) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) load4(bp + 32 * mt + 8 * g + 4 * h, bv[g]);
+    };
+    auto zero_acc = [&](f32x16 (&acc)[MTW][NT]) {
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[m][nt][i] = 0.f;
     };
 
     __syncthreads();  // first X landed
@@ -581,98 +601,105 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
         const bool lo = t0 == 0, hi = L - 1 - t0 + 4 < N;  // position L-1 sits among this tile's columns
         const int c_first = 4 - t0, c_last = L - 1 - t0 + 4;  // columns of positions 0 and L-1
 
-        f32x16 acc[NT];
-        // ---- ConvBlock(k): X(P) -> A1(Q), rows = column + 3
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
-        mma_layer<DT, CIN, NT>(P, col0, ks1, w1, acc);
+        f32x16 acc[MTW][NT];
         float bv[4][4];
-        load_bias(a.b1, bv);
-        store_act_lds<DT, NT>(Q, col0 + 3, acc, bv, mt, h);
+        // ---- ConvBlock(k): X(P) -> A1(Q), rows = column + 3
+        zero_acc(acc);
+        mma_layer<DT, CIN, NT, MTW>(P, col0, ks1, w1, acc);
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            load_bias(a.b1, mt0 + m, bv);
+            store_act_lds<DT, NT>(Q, col0 + 3, acc[m], bv, mt0 + m, h);
+        }
         __syncthreads();  // B1
         if (lo || hi) {
             if (wave == 0) fix_edges<DT>(Q, 3, 3, c_first, c_last, lo, hi, lane);
             __syncthreads();
         }
         // ---- ConvBlock(7): A1(Q) -> A2(P), rows = column + 1
+        zero_acc(acc);
+        mma_layer<DT, 128, NT, MTW>(Q, col0, 7, w2, acc);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
-        mma_layer<DT, 128, NT>(Q, col0, 7, w2, acc);
-        load_bias(a.b2, bv);
-        store_act_lds<DT, NT>(P, col0 + 1, acc, bv, mt, h);
+        for (int m = 0; m < MTW; ++m) {
+            load_bias(a.b2, mt0 + m, bv);
+            store_act_lds<DT, NT>(P, col0 + 1, acc[m], bv, mt0 + m, h);
+        }
         __syncthreads();  // B2
         if (lo || hi) {
             if (wave == 0) fix_edges<DT>(P, 1, 1, c_first, c_last, lo, hi, lane);
             __syncthreads();
         }
         // ---- ConvBlock(3): A2(P) -> registers
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
-        mma_layer<DT, 128, NT>(P, col0, 3, w3, acc);
-        load_bias(a.b3, bv);
+        zero_acc(acc);
+        mma_layer<DT, 128, NT, MTW>(P, col0, 3, w3, acc);
 
         if constexpr (!HEAD) {
             // relu(conv3 + b3) in registers, then the 1x1 skip accumulates on top by MFMA
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int m = 0; m < MTW; ++m) {
+                load_bias(a.b3, mt0 + m, bv);
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[nt][4 * g + i] = fmaxf(acc[nt][4 * g + i] + bv[g][i], 0.f);
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[m][nt][4 * g + i] = fmaxf(acc[m][nt][4 * g + i] + bv[g][i], 0.f);
+            }
             if constexpr (HAS_RES) {
                 __syncthreads();  // BR: centre rows of X landed in Q + xb
-                const uint4* wr = a.wr + (size_t)mt * NCPI * 64 + lane;
-                mma_layer<DT, CIN, NT>(Q + xb, col0, 1, wr, acc);
-            }
-            float brv[4][4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (HAS_RES) load4(a.br + 32 * mt + 8 * g + 4 * h, brv[g]);
-                else brv[g][0] = brv[g][1] = brv[g][2] = brv[g][3] = 0.f;
+                const uint4* wr = a.wr + (size_t)mt0 * NCPI * 64 + lane;
+                mma_layer<DT, CIN, NT, MTW>(Q + xb, col0, 1, wr, acc);
             }
             DT* outp = reinterpret_cast<DT*>(a.out);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int c = col0 + nt * 32;
-                const int p = t0 - 4 + c;
-                if (c >= 4 && c < 4 + T && p < L) {
-                    const size_t o = ((size_t)b * L + p) * 128 + 32 * mt + 4 * h;
+            for (int m = 0; m < MTW; ++m) {
+                const int mt = mt0 + m;
+                if (HAS_RES) load_bias(a.br, mt, bv);
+                else
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        store4(outp + o + 8 * g, acc[nt][4 * g + 0] + brv[g][0], acc[nt][4 * g + 1] + brv[g][1],
-                               acc[nt][4 * g + 2] + brv[g][2], acc[nt][4 * g + 3] + brv[g][3]);
+                    for (int g = 0; g < 4; ++g) bv[g][0] = bv[g][1] = bv[g][2] = bv[g][3] = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int c = col0 + nt * 32;
+                    const int p = t0 - 4 + c;
+                    if (c >= 4 && c < 4 + T && p < L) {
+                        const size_t o = ((size_t)b * L + p) * 128 + 32 * mt + 4 * h;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            store4(outp + o + 8 * g, acc[m][nt][4 * g + 0] + bv[g][0], acc[m][nt][4 * g + 1] + bv[g][1],
+                                   acc[m][nt][4 * g + 2] + bv[g][2], acc[m][nt][4 * g + 3] + bv[g][3]);
+                    }
                 }
             }
         } else {
-            float w0[4][4], w1v[4][4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                load4(a.wfc + 32 * mt + 8 * g + 4 * h, w0[g]);
-                load4(a.wfc + 128 + 32 * mt + 8 * g + 4 * h, w1v[g]);
-            }
+            for (int m = 0; m < MTW; ++m) {
+                const int mt = mt0 + m;
+                float w0[4][4], w1v[4][4];
+                load_bias(a.b3, mt, bv);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                float c0 = 0.f, c1 = 0.f;
+                for (int g = 0; g < 4; ++g) {
+                    load4(a.wfc + 32 * mt + 8 * g + 4 * h, w0[g]);
+                    load4(a.wfc + 128 + 32 * mt + 8 * g + 4 * h, w1v[g]);
+                }
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
+                for (int nt = 0; nt < NT; ++nt) {
+                    float c0 = 0.f, c1 = 0.f;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float f = fmaxf(acc[nt][4 * g + i] + bv[g][i], 0.f);
-                        c0 = fmaf(w0[g][i], f, c0);
-                        c1 = fmaf(w1v[g][i], f, c1);
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float f = fmaxf(acc[m][nt][4 * g + i] + bv[g][i], 0.f);
+                            c0 = fmaf(w0[g][i], f, c0);
+                            c1 = fmaf(w1v[g][i], f, c1);
+                        }
+                    c0 += __shfl_xor(c0, 32);
+                    c1 += __shfl_xor(c1, 32);
+                    if (h == 0) {
+                        const int c = col0 + nt * 32;
+                        red[(mt * N + c) * 2 + 0] = c0;
+                        red[(mt * N + c) * 2 + 1] = c1;
                     }
-                c0 += __shfl_xor(c0, 32);
-                c1 += __shfl_xor(c1, 32);
-                if (h == 0) {
-                    const int c = col0 + nt * 32;
-                    red[(mt * N + c) * 2 + 0] = c0;
-                    red[(mt * N + c) * 2 + 1] = c1;
                 }
             }
             __syncthreads();

@@ -170,7 +170,8 @@ class TrainEngine:
         x = x.to(self.device).contiguous()
         y = None
         if labels is not None:
-            y = torch.as_tensor(np.asarray(labels)).to(self.device).float().long().to(torch.int32).contiguous()
+            y = labels if torch.is_tensor(labels) else torch.as_tensor(np.asarray(labels))
+            y = y.to(self.device).float().long().to(torch.int32).contiguous()
         return x, y
 
     def forward_backward(self, ts, labels, update_running=True):
