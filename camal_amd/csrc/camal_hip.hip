@@ -87,6 +87,7 @@ struct ProfRec { int cls; hipEvent_t a, b; };
 
 struct camal_ctx {
     int device = 0, E = 0, precision = 0, chunk = 256, cam_row = 1;
+    int post_windows = 4096;  // windows per post-processing launch (their CAM rows wait in the workspace)
     int num_cu = 256;
     size_t lds_per_cu = 160 * 1024;
     int fused = 1;  // blocks 2 and 3 as fused-block kernels (block_kernel); 0: one conv_kernel per layer
@@ -161,7 +162,7 @@ int make_layer(camal_ctx* c, Layer& ly, const float* w, const float* b, int cout
 // ---- workspace ------------------------------------------------------------------------
 struct Workspace {
     void *a1, *b1, *r1, *a2, *b2, *r2;
-    float *cam, *part, *logits;
+    float *cam, *part, *logits, *cmax;
     int ntiles;
 };
 
@@ -216,7 +217,8 @@ int head_tile_len(const camal_ctx* c, bool fused, int k) {
 // upper bound over every path (workspace sizing): the smallest head tile is 56 timesteps
 int head_tiles(const camal_ctx*, int L) { return (L + 55) / 56; }
 
-size_t workspace_layout(const camal_ctx* c, int BC, int L, Workspace* w, char* base) {
+// BC: windows per conv pass (activations); PB >= BC: windows per post-processing launch (CAM rows, logits)
+size_t workspace_layout(const camal_ctx* c, int BC, int PB, int L, Workspace* w, char* base) {
     const size_t es = c->precision == CAMAL_FP32 ? 4 : 2;
     const size_t n64 = align_up((size_t)BC * L * C1 * es), n128 = align_up((size_t)BC * L * C2 * es);
     const int ntiles = head_tiles(c, L);
@@ -225,16 +227,17 @@ size_t workspace_layout(const camal_ctx* c, int BC, int L, Workspace* w, char* b
     Workspace t;
     t.a1 = take(n64); t.b1 = take(n64); t.r1 = take(n64);
     t.a2 = take(n128); t.b2 = take(n128); t.r2 = take(n128);
-    t.cam = (float*)take(align_up((size_t)c->E * BC * L * 4));
-    t.part = (float*)take(align_up((size_t)c->E * BC * ntiles * 2 * 4));
-    t.logits = (float*)take(align_up((size_t)c->E * BC * 2 * 4));
+    t.cam = (float*)take(align_up((size_t)c->E * PB * L * 4));
+    t.part = (float*)take(align_up((size_t)BC * ntiles * 2 * 4));
+    t.logits = (float*)take(align_up((size_t)c->E * PB * 2 * 4));
+    t.cmax = (float*)take(align_up((size_t)c->E * PB * 4));
     t.ntiles = ntiles;
     if (w) *w = t;
     return off;
 }
 
-int ensure_workspace(camal_ctx* c, int BC, int L, Workspace* w) {
-    size_t need = workspace_layout(c, BC, L, nullptr, nullptr);
+int ensure_workspace(camal_ctx* c, int BC, int PB, int L, Workspace* w) {
+    size_t need = workspace_layout(c, BC, PB, L, nullptr, nullptr);
     if (need > c->ws_bytes) {
         if (c->ws) HIP_TRY(hipFree(c->ws));
         c->ws = nullptr; c->ws_bytes = 0;
@@ -242,7 +245,7 @@ int ensure_workspace(camal_ctx* c, int BC, int L, Workspace* w) {
         if (e != hipSuccess) return fail(CAMAL_ERR_NOMEM, "workspace hipMalloc of " + std::to_string(need) + " bytes failed");
         c->ws_bytes = need;
     }
-    workspace_layout(c, BC, L, w, c->ws);
+    workspace_layout(c, BC, PB, L, w, c->ws);
     return 0;
 }
 
@@ -272,7 +275,7 @@ struct ProfScope {
 template <typename DT, int CIN, int COUT, int NWC, bool RELU, bool HAS_RES, bool HEAD>
 int launch_conv_w(camal_ctx* c, int num_cu, size_t lds_per_cu, int cam_row, hipStream_t s, const void* wpack,
                   const float* bias, int ks, const void* in, const void* res, void* out, const float* wfc, float* cam,
-                  float* part, int BC, int L_out, int L_in, int in_off, const void* zero_row) {
+                  float* part, int BC, int L_out, int L_in, int in_off, const void* zero_row, float* cmax = nullptr) {
     using G = GeomW<DT, CIN, COUT, NWC>;
     auto kern = conv_kernel<DT, CIN, COUT, G::TN / (32 * G::NG), NWC, RELU, HAS_RES, HEAD>;
     const size_t lds = 2 * (size_t)G::buf_bytes(ks) + (HEAD ? G::HEAD_BYTES : 0);
@@ -290,7 +293,7 @@ int launch_conv_w(camal_ctx* c, int num_cu, size_t lds_per_cu, int cam_row, hipS
     ProfScope ps(c, s, HEAD ? 2 : 1);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(G::THREADS), lds, s, (const DT*)in, (const uint4*)wpack, bias,
                        (const DT*)res, (DT*)out, wfc, cam, part, L_out, ks, cam_row, tpw, (int)total, L_in, in_off,
-                       (const DT*)zero_row);
+                       (const DT*)zero_row, cmax);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -298,27 +301,27 @@ int launch_conv_w(camal_ctx* c, int num_cu, size_t lds_per_cu, int cam_row, hipS
 template <typename DT, int CIN, int COUT, bool RELU, bool HAS_RES, bool HEAD>
 int launch_conv_ex(camal_ctx* c, int num_cu, size_t lds_per_cu, int cam_row, hipStream_t s, const void* wpack,
                    const float* bias, int ks, const void* in, const void* res, void* out, const float* wfc, float* cam,
-                   float* part, int BC, int L_out, int L_in, int in_off, const void* zero_row) {
+                   float* part, int BC, int L_out, int L_in, int in_off, const void* zero_row, float* cmax = nullptr) {
     if (use_small_wg<DT, CIN, COUT, HEAD>(lds_per_cu, ks))
         return launch_conv_w<DT, CIN, COUT, 4, RELU, HAS_RES, HEAD>(c, num_cu, lds_per_cu, cam_row, s, wpack, bias, ks, in, res,
-                                                                    out, wfc, cam, part, BC, L_out, L_in, in_off, zero_row);
+                                                                    out, wfc, cam, part, BC, L_out, L_in, in_off, zero_row, cmax);
     if constexpr (sizeof(DT) == 4)
         return launch_conv_w<DT, CIN, COUT, 8, RELU, HAS_RES, HEAD>(c, num_cu, lds_per_cu, cam_row, s, wpack, bias, ks, in, res,
-                                                                    out, wfc, cam, part, BC, L_out, L_in, in_off, zero_row);
+                                                                    out, wfc, cam, part, BC, L_out, L_in, in_off, zero_row, cmax);
     return fail(CAMAL_ERR_ARG, "kernel size too large for the LDS tile");
 }
 
 template <typename DT, int CIN, int COUT, bool RELU, bool HAS_RES, bool HEAD>
 int launch_conv(camal_ctx* c, hipStream_t s, const Layer& ly, const void* in, const void* res, void* out,
-                const float* wfc, float* cam, float* part, int BC, int L) {
+                const float* wfc, float* cam, float* part, int BC, int L, float* cmax = nullptr) {
     return launch_conv_ex<DT, CIN, COUT, RELU, HAS_RES, HEAD>(c, c->num_cu, c->lds_per_cu, c->cam_row, s, ly.wpack,
                                                               ly.bias, ly.ks, in, res, out, wfc, cam, part, BC, L, L,
-                                                              ly.ks >> 1, nullptr);
+                                                              ly.ks >> 1, nullptr, cmax);
 }
 
 template <typename DT, int CIN, int NWC, bool HAS_RES, bool HEAD>
 int launch_block_w(camal_ctx* c, hipStream_t s, const Layer& l1, const Layer& l2, const Layer& l3, const Layer* lr,
-                   const void* in, void* out, const float* wfc, float* cam, float* part, int BC, int L) {
+                   const void* in, void* out, const float* wfc, float* cam, float* part, int BC, int L, float* cmax) {
     constexpr int NTB = BlockNT<DT>::NT;
     using G = BGeom<DT, CIN, NWC>;
     auto kern = block_kernel<DT, CIN, NTB, NWC, 8 / NWC, HAS_RES, HEAD>;
@@ -333,7 +336,7 @@ int launch_block_w(camal_ctx* c, hipStream_t s, const Layer& l1, const Layer& l2
     a.w1 = (const uint4*)l1.wpack; a.w2 = (const uint4*)l2.wpack; a.w3 = (const uint4*)l3.wpack;
     a.wr = lr ? (const uint4*)lr->wpack : nullptr;
     a.b1 = l1.bias; a.b2 = l2.bias; a.b3 = l3.bias; a.br = lr ? lr->bias : nullptr;
-    a.wfc = wfc; a.cam = cam; a.part = part;
+    a.wfc = wfc; a.cam = cam; a.part = part; a.cmax = cmax;
     a.L = L; a.ks1 = l1.ks; a.cam_row = c->cam_row;
     a.tiles_per_window = (L + G::T - 1) / G::T;
     const long long total = (long long)a.tiles_per_window * BC;
@@ -349,17 +352,18 @@ int launch_block_w(camal_ctx* c, hipStream_t s, const Layer& l1, const Layer& l2
 
 template <typename DT, int CIN, bool HAS_RES, bool HEAD>
 int launch_block(camal_ctx* c, hipStream_t s, const Layer& l1, const Layer& l2, const Layer& l3, const Layer* lr,
-                 const void* in, void* out, const float* wfc, float* cam, float* part, int BC, int L) {
+                 const void* in, void* out, const float* wfc, float* cam, float* part, int BC, int L,
+                 float* cmax = nullptr) {
     const int nwc = block_nwc<DT, CIN, HAS_RES, HEAD>(c->lds_per_cu, l1.ks);
-    if (nwc == 4) return launch_block_w<DT, CIN, 4, HAS_RES, HEAD>(c, s, l1, l2, l3, lr, in, out, wfc, cam, part, BC, L);
-    if (nwc == 8) return launch_block_w<DT, CIN, 8, HAS_RES, HEAD>(c, s, l1, l2, l3, lr, in, out, wfc, cam, part, BC, L);
+    if (nwc == 4) return launch_block_w<DT, CIN, 4, HAS_RES, HEAD>(c, s, l1, l2, l3, lr, in, out, wfc, cam, part, BC, L, cmax);
+    if (nwc == 8) return launch_block_w<DT, CIN, 8, HAS_RES, HEAD>(c, s, l1, l2, l3, lr, in, out, wfc, cam, part, BC, L, cmax);
     return fail(CAMAL_ERR_ARG, "kernel size too large for the fused block tile");
 }
 
 // One member's conv stack on BC windows: x -> cam row 1 [BC][L] + pooled partials [BC][ntiles][2]
 template <typename DT>
 int run_member(camal_ctx* c, hipStream_t s, const Member& m, const float* x, int BC, int L, const Workspace& w,
-               float* cam, float* part) {
+               float* cam, float* part, float* cmax) {
     {
         ProfScope ps(c, s, 0);
         hipLaunchKernelGGL(stem_kernel<DT>, dim3((L + 63) / 64, BC), dim3(256), 0, s, x, m.stem_w, m.stem_b, m.res1_w,
@@ -373,7 +377,7 @@ int run_member(camal_ctx* c, hipStream_t s, const Member& m, const float* x, int
     if (c->fused && fused_fits(c, m.k)) {
         // blocks 2 and 3: one fused kernel each (three ConvBlocks through LDS)
         if ((r = launch_block<DT, C1, true, false>(c, s, m.conv[2], m.conv[3], m.conv[4], &m.res2, w.a1, w.a2, nullptr, nullptr, nullptr, BC, L))) return r;
-        if ((r = launch_block<DT, C2, false, true>(c, s, m.conv[5], m.conv[6], m.conv[7], nullptr, w.a2, nullptr, m.wfc, cam, part, BC, L))) return r;
+        if ((r = launch_block<DT, C2, false, true>(c, s, m.conv[5], m.conv[6], m.conv[7], nullptr, w.a2, nullptr, m.wfc, cam, part, BC, L, cmax))) return r;
         return 0;
     }
     // block 2: residual BN(Conv1x1) first (no ReLU), then ConvBlock(k), (7), (3)+residual
@@ -384,14 +388,14 @@ int run_member(camal_ctx* c, hipStream_t s, const Member& m, const float* x, int
     // block 3: no skip (camal_resnet.py:40-41,59); last ConvBlock fused with the CAM head
     if ((r = launch_conv<DT, C2, C2, true, false, false>(c, s, m.conv[5], w.a2, nullptr, w.b2, nullptr, nullptr, nullptr, BC, L))) return r;
     if ((r = launch_conv<DT, C2, C2, true, false, false>(c, s, m.conv[6], w.b2, nullptr, w.a2, nullptr, nullptr, nullptr, BC, L))) return r;
-    if ((r = launch_conv<DT, C2, C2, true, false, true>(c, s, m.conv[7], w.a2, nullptr, nullptr, m.wfc, cam, part, BC, L))) return r;
+    if ((r = launch_conv<DT, C2, C2, true, false, true>(c, s, m.conv[7], w.a2, nullptr, nullptr, m.wfc, cam, part, BC, L, cmax))) return r;
     return 0;
 }
 
 int run_member_any(camal_ctx* c, hipStream_t s, const Member& m, const float* x, int BC, int L, const Workspace& w,
-                   float* cam, float* part, float* logits) {
-    int r = c->precision == CAMAL_FP32 ? run_member<float>(c, s, m, x, BC, L, w, cam, part)
-                                       : run_member<__bf16>(c, s, m, x, BC, L, w, cam, part);
+                   float* cam, float* part, float* logits, float* cmax) {
+    int r = c->precision == CAMAL_FP32 ? run_member<float>(c, s, m, x, BC, L, w, cam, part, cmax)
+                                       : run_member<__bf16>(c, s, m, x, BC, L, w, cam, part, cmax);
     if (r) return r;
     ProfScope ps(c, s, 4);
     const int tl = head_tile_len(c, c->fused && fused_fits(c, m.k), m.k);
@@ -409,10 +413,25 @@ int check_ctx(camal_ctx* c, int B, int L) {
     return 0;
 }
 
-int launch_post(camal_ctx* c, hipStream_t s, const PostArgs& a) {
+// own_max: the rows' maxima are not in a.cmax; the kernel scans the rows for them
+int launch_post(camal_ctx* c, hipStream_t s, const PostArgs& a0, bool own_max) {
     ProfScope ps(c, s, 3);
-    hipLaunchKernelGGL(post_kernel, dim3(a.B), dim3(256), 0, s, a);
-    HIP_TRY(hipGetLastError());
+    const int tiles = (a0.L + POST_TILE - 1) / POST_TILE;
+    constexpr int kMaxY = 32768;  // grid.y limit is 65535
+    for (int b0 = 0; b0 < a0.B; b0 += kMaxY) {
+        PostArgs a = a0;
+        const size_t o = (size_t)b0 * a0.L;
+        a.B = std::min(kMaxY, a0.B - b0);
+        a.cam += o; a.logits += 2 * (size_t)b0; if (a.cmax) a.cmax += b0;
+        a.x += o; if (a.x64) a.x64 += o; if (a.y) a.y += b0;
+        a.prob_out += b0; a.state_out += o; if (a.avg_out) a.avg_out += o; if (a.power_out) a.power_out += o;
+        const dim3 grid(tiles, a.B), block(256);
+        // 4 members per load round: 5 or 8 per round cost more registers (occupancy) than the round trip
+        // they save (measured on E = 5: 44.7 us with 4, 45.7 with 5, 53.9 with 8, per 4096 x 1440 launch)
+        if (own_max) hipLaunchKernelGGL((post_kernel<true, 4>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((post_kernel<false, 4>), grid, block, 0, s, a);
+        HIP_TRY(hipGetLastError());
+    }
     return 0;
 }
 
@@ -441,6 +460,7 @@ int camal_create(int device_id, int n_members, const int* kernel_sizes, int prec
     // bound (bf16), a 6 % loss of MFMA work where it is already MFMA-bound (fp32, 128-column tiles)
     c->fused = precision == CAMAL_BF16;
     if (const char* e = getenv("CAMAL_FUSED")) c->fused = atoi(e) != 0;
+    if (const char* e = getenv("CAMAL_POST_WINDOWS")) c->post_windows = std::max(1, atoi(e));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
     c->m.resize(n_members);
@@ -517,13 +537,13 @@ int camal_forward_cam(camal_ctx* c, const float* x, int B, int L, int member, in
     hipStream_t s = (hipStream_t)stream;
     const int BC = std::min(B, c->chunk);
     Workspace w;
-    if (int r = ensure_workspace(c, BC, L, &w)) return r;
+    if (int r = ensure_workspace(c, BC, BC, L, &w)) return r;
     const int e0 = member < 0 ? 0 : member, e1 = member < 0 ? c->E : member + 1, EO = e1 - e0;
     for (int c0 = 0; c0 < B; c0 += BC) {
         const int n = std::min(BC, B - c0);
         for (int e = e0; e < e1; ++e) {
             float* camw = w.cam;  // member rows are consumed immediately: one row buffer is enough
-            if (int r = run_member_any(c, s, c->m[e], x + (size_t)c0 * L, n, L, w, camw, w.part, w.logits)) return r;
+            if (int r = run_member_any(c, s, c->m[e], x + (size_t)c0 * L, n, L, w, camw, w.part, w.logits, nullptr)) return r;
             HIP_TRY(hipMemcpyAsync(logits + ((size_t)(e - e0) * B + c0) * 2, w.logits, (size_t)n * 2 * 4, hipMemcpyDeviceToDevice, s));
             if (cam) HIP_TRY(hipMemcpyAsync(cam + ((size_t)(e - e0) * B + c0) * L, camw, (size_t)n * L * 4, hipMemcpyDeviceToDevice, s));
         }
@@ -541,11 +561,12 @@ int camal_postprocess(int E, const float* cam, const float* logits, const float*
     if (B < 1 || L < 1) return fail(CAMAL_ERR_ARG, "B and L must be >= 1");
     if (w_ma < 1 || w_ma > 64) return fail(CAMAL_ERR_ARG, "w_ma must be in 1..64");
     PostArgs a;
-    a.cam = cam; a.logits = logits; a.x = x; a.x64 = x64; a.y = y;
+    a.cam = cam; a.logits = logits; a.cmax = nullptr; a.x = x; a.x64 = x64; a.y = y;
+    a.cam_estride = (size_t)B * L; a.lg_estride = (size_t)B * 2; a.cmax_estride = 0;
     a.prob_out = prob_out; a.avg_out = avg_cam_out; a.state_out = state_out; a.power_out = power_out;
     a.E = E; a.B = B; a.L = L; a.w_ma = w_ma; a.gate_mode = gate_mode; a.pred_f64 = pred_f64;
     a.p_on = p_on; a.scale_mul = scale_mul; a.scale_add = scale_add;
-    return launch_post(nullptr, (hipStream_t)stream, a);
+    return launch_post(nullptr, (hipStream_t)stream, a, true);
 }
 
 int camal_localize(camal_ctx* c, const float* x, const double* x64, const int8_t* y, int B, int L, int w_ma,
@@ -559,29 +580,40 @@ int camal_localize(camal_ctx* c, const float* x, const double* x64, const int8_t
     hipStream_t s = (hipStream_t)stream;
     c->cam_row = 1;  // core.py:302-303 always asks for the CAM of label 1
     const int BC = std::min(B, c->chunk), E = c->E;
+    // windows per post-processing launch: a whole number of conv passes, at most post_windows and at most
+    // 1 GiB of waiting CAM rows
+    const long long fit = (1LL << 30) / ((long long)E * L * 4);
+    const int PB = std::min(B, std::max(BC, (int)std::min<long long>(c->post_windows, fit) / BC * BC));
     Workspace w;
-    if (int r = ensure_workspace(c, BC, L, &w)) return r;
-    for (int c0 = 0; c0 < B; c0 += BC) {
-        const int n = std::min(BC, B - c0);
-        for (int e = 0; e < E; ++e) {
-            // chunk-local layout [E][n][..] so that the post kernel's member stride is n*L
-            float* camw = w.cam + (size_t)e * n * L;
-            float* lgw = w.logits + (size_t)e * n * 2;
-            float* partw = w.part + (size_t)e * n * w.ntiles * 2;
-            if (int r = run_member_any(c, s, c->m[e], x + (size_t)c0 * L, n, L, w, camw, partw, lgw)) return r;
-            if (member_logits_out)
-                HIP_TRY(hipMemcpyAsync(member_logits_out + ((size_t)e * B + c0) * 2, lgw, (size_t)n * 2 * 4, hipMemcpyDeviceToDevice, s));
-            if (member_cam_out)
-                HIP_TRY(hipMemcpyAsync(member_cam_out + ((size_t)e * B + c0) * L, camw, (size_t)n * L * 4, hipMemcpyDeviceToDevice, s));
+    if (int r = ensure_workspace(c, BC, PB, L, &w)) return r;
+    for (int g0 = 0; g0 < B; g0 += PB) {
+        // one post-processing launch per group of ng windows; the group's CAM rows, logits and row maxima
+        // wait in the workspace as [E][ng][..]
+        const int ng = std::min(PB, B - g0);
+        HIP_TRY(hipMemsetAsync(w.cmax, 0, (size_t)E * ng * 4, s));
+        for (int c0 = g0; c0 < g0 + ng; c0 += BC) {
+            const int n = std::min(BC, g0 + ng - c0);
+            for (int e = 0; e < E; ++e) {
+                float* camw = w.cam + ((size_t)e * ng + (c0 - g0)) * L;
+                float* lgw = w.logits + ((size_t)e * ng + (c0 - g0)) * 2;
+                float* cmw = w.cmax + (size_t)e * ng + (c0 - g0);
+                if (int r = run_member_any(c, s, c->m[e], x + (size_t)c0 * L, n, L, w, camw, w.part, lgw, cmw)) return r;
+                if (member_logits_out)
+                    HIP_TRY(hipMemcpyAsync(member_logits_out + ((size_t)e * B + c0) * 2, lgw, (size_t)n * 2 * 4, hipMemcpyDeviceToDevice, s));
+                if (member_cam_out)
+                    HIP_TRY(hipMemcpyAsync(member_cam_out + ((size_t)e * B + c0) * L, camw, (size_t)n * L * 4, hipMemcpyDeviceToDevice, s));
+            }
         }
         PostArgs a;
-        a.cam = w.cam; a.logits = w.logits; a.x = x + (size_t)c0 * L; a.x64 = x64 ? x64 + (size_t)c0 * L : nullptr;
-        a.y = y ? y + c0 : nullptr;
-        a.prob_out = prob_out + c0; a.avg_out = avg_cam_out ? avg_cam_out + (size_t)c0 * L : nullptr;
-        a.state_out = state_out + (size_t)c0 * L; a.power_out = power_out ? power_out + (size_t)c0 * L : nullptr;
-        a.E = E; a.B = n; a.L = L; a.w_ma = w_ma; a.gate_mode = gate_mode; a.pred_f64 = pred_f64;
+        a.cam = w.cam; a.logits = w.logits; a.cmax = w.cmax;
+        a.cam_estride = (size_t)ng * L; a.lg_estride = (size_t)ng * 2; a.cmax_estride = (size_t)ng;
+        a.x = x + (size_t)g0 * L; a.x64 = x64 ? x64 + (size_t)g0 * L : nullptr;
+        a.y = y ? y + g0 : nullptr;
+        a.prob_out = prob_out + g0; a.avg_out = avg_cam_out ? avg_cam_out + (size_t)g0 * L : nullptr;
+        a.state_out = state_out + (size_t)g0 * L; a.power_out = power_out ? power_out + (size_t)g0 * L : nullptr;
+        a.E = E; a.B = ng; a.L = L; a.w_ma = w_ma; a.gate_mode = gate_mode; a.pred_f64 = pred_f64;
         a.p_on = p_on; a.scale_mul = scale_mul; a.scale_add = scale_add;
-        if (int r = launch_post(c, s, a)) return r;
+        if (int r = launch_post(c, s, a, false)) return r;
     }
     return 0;
 }

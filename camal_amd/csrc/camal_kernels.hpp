@@ -222,6 +222,13 @@ __device__ __forceinline__ void mma_layer(const char* buf, int R0, int ks, const
     }
 }
 
+// core.py:308-310 on one CAM value: clip below at 0, NaN and +inf -> 0
+__device__ __forceinline__ float clip_cam(float v) {
+    // np.clip(a_min=0) then nan_to_num(nan=0, posinf=0): only positive finite values survive, and those
+    // are exactly the bit patterns below +inf's when read as unsigned (sign bit set = negative or -0)
+    return __float_as_uint(v) < 0x7f800000u ? v : 0.f;
+}
+
 template <typename DT, int CIN, int COUT, int NT, int NWC>
 struct ConvGeom {
     static constexpr int ES = sizeof(DT);
@@ -232,7 +239,7 @@ struct ConvGeom {
     static constexpr int NG = NWC / MT;                        // column groups across compute waves
     static constexpr int THREADS = (NWC + 1) * 64;             // + the loader wave
     static constexpr int TN = NG * NT * 32;                    // timesteps per tile
-    static constexpr int HEAD_BYTES = (MT * TN * 2 + 2 * NWC) * 4;  // CAM-head reduction scratch
+    static constexpr int HEAD_BYTES = (MT * TN * 2 + 3 * NWC) * 4;  // CAM-head reduction scratch
     __host__ __device__ static constexpr int buf_bytes(int ks) { return (((TN + ks - 1) * RB) + 1023) & ~1023; }
 };
 
@@ -251,7 +258,10 @@ __global__ __launch_bounds__((NWC + 1) * 64) void conv_kernel(const DT* __restri
                                                             // input row for (output t, tap j) = t + j - in_off,
                                                             // valid in [0, L_in); outside: clamp (replicate) or,
                                                             // if zero_row != null, a row of zeros.
-                                                            int L_in, int in_off, const DT* __restrict__ zero_row) {
+                                                            int L_in, int in_off, const DT* __restrict__ zero_row,
+                                                            // HEAD, optional: per-window max of the clipped CAM row
+                                                            // (core.py:311), folded in with one atomic max per tile
+                                                            float* __restrict__ cmax) {
     using G = ConvGeom<DT, CIN, COUT, NT, NWC>;
     constexpr int RB = G::RB, CPR = G::CPR, NCP = G::NCP, MT = G::MT, TN = G::TN;
     static_assert(MT == 2 || MT == 4, "COUT must be 64 or 128");
@@ -377,7 +387,7 @@ __global__ __launch_bounds__((NWC + 1) * 64) void conv_kernel(const DT* __restri
                 }
             }
             __syncthreads();
-            float s0 = 0.f, s1 = 0.f;
+            float s0 = 0.f, s1 = 0.f, mx = 0.f;
             for (int tl = threadIdx.x; tl < TN; tl += NWC * 64) {
                 float c0 = 0.f, c1 = 0.f;
 #pragma unroll
@@ -387,27 +397,32 @@ __global__ __launch_bounds__((NWC + 1) * 64) void conv_kernel(const DT* __restri
                 }
                 const int t = t0 + tl;
                 if (t < L) {
-                    cam_out[(size_t)b * L + t] = cam_row ? c1 : c0;
+                    const float cv = cam_row ? c1 : c0;
+                    cam_out[(size_t)b * L + t] = cv;
+                    mx = fmaxf(mx, clip_cam(cv));
                     s0 += c0;
                     s1 += c1;
                 }
             }
-            // tile sums of both rows: wave shuffle tree, then NWC partials through LDS
+            // tile sums of both rows (+ max of the clipped CAM): wave shuffle tree, then NWC partials through LDS
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 s0 += __shfl_xor(s0, o);
                 s1 += __shfl_xor(s1, o);
+                mx = fmaxf(mx, __shfl_xor(mx, o));
             }
             float* red2 = red + MT * TN * 2;
-            if (lane == 0) { red2[2 * wave] = s0; red2[2 * wave + 1] = s1; }
+            if (lane == 0) { red2[3 * wave] = s0; red2[3 * wave + 1] = s1; red2[3 * wave + 2] = mx; }
             __syncthreads();
             if (threadIdx.x == 0) {
                 float* po = part_out + ((size_t)b * tiles_per_window + tx) * 2;
-                float p0 = 0.f, p1 = 0.f;
+                float p0 = 0.f, p1 = 0.f, pm = 0.f;
 #pragma unroll
-                for (int wv = 0; wv < NWC; ++wv) { p0 += red2[2 * wv]; p1 += red2[2 * wv + 1]; }
+                for (int wv = 0; wv < NWC; ++wv) { p0 += red2[3 * wv]; p1 += red2[3 * wv + 1]; pm = fmaxf(pm, red2[3 * wv + 2]); }
                 po[0] = p0;
                 po[1] = p1;
+                // non-negative floats order like their bit patterns
+                if (cmax != nullptr && pm > 0.f) atomicMax(reinterpret_cast<unsigned int*>(cmax) + b, __float_as_uint(pm));
             }
         }
         __syncthreads();  // next tile landed (loader) and this buffer is free to refill
@@ -484,6 +499,7 @@ struct BlockArgs {
     const float* wfc;  // [2][128]     (block 3)
     float* cam;        // [B][L]
     float* part;       // [B][tiles_per_window][2]
+    float* cmax;       // [B] or null: running max of the clipped CAM row (atomic max per head tile)
     int L, ks1, cam_row, tiles_per_window, total_tiles;
 };
 
@@ -495,7 +511,7 @@ struct BlockGeom {
     static constexpr int T = N - 8;            // valid columns per tile (halo 4 each side after convs 7 and 3)
     static constexpr int RBI = CIN * ES;       // X row bytes
     static constexpr int RBA = 128 * ES;       // A1 / A2 row bytes
-    static constexpr int HEAD_BYTES = (4 * N * 2 + 2 * NWC) * 4;
+    static constexpr int HEAD_BYTES = (4 * N * 2 + 3 * NWC) * 4;
     __host__ __device__ static constexpr int x_bytes(int ks) { return (((N + ks - 1) * RBI) + 1023) & ~1023; }
     __host__ __device__ static constexpr int xc_bytes() { return ((N * RBI) + 1023) & ~1023; }
     // one buffer must hold X, or A1 (N + 6 rows), or [next X | centre rows of X] (HAS_RES)
@@ -703,7 +719,7 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
                 }
             }
             __syncthreads();
-            float s0 = 0.f, s1 = 0.f;
+            float s0 = 0.f, s1 = 0.f, mx = 0.f;
             for (int c = threadIdx.x; c < N; c += NWC * 64) {
                 float c0 = 0.f, c1 = 0.f;
 #pragma unroll
@@ -713,7 +729,9 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
                 }
                 const int p = t0 - 4 + c;
                 if (c >= 4 && c < 4 + T && p < L) {
-                    a.cam[(size_t)b * L + p] = a.cam_row ? c1 : c0;
+                    const float cv = a.cam_row ? c1 : c0;
+                    a.cam[(size_t)b * L + p] = cv;
+                    mx = fmaxf(mx, clip_cam(cv));
                     s0 += c0;
                     s1 += c1;
                 }
@@ -722,17 +740,19 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
             for (int o = 32; o > 0; o >>= 1) {
                 s0 += __shfl_xor(s0, o);
                 s1 += __shfl_xor(s1, o);
+                mx = fmaxf(mx, __shfl_xor(mx, o));
             }
             float* red2 = red + 4 * N * 2;
-            if (lane == 0) { red2[2 * wave] = s0; red2[2 * wave + 1] = s1; }
+            if (lane == 0) { red2[3 * wave] = s0; red2[3 * wave + 1] = s1; red2[3 * wave + 2] = mx; }
             __syncthreads();
             if (threadIdx.x == 0) {
-                float p0 = 0.f, p1 = 0.f;
+                float p0 = 0.f, p1 = 0.f, pm = 0.f;
 #pragma unroll
-                for (int wv = 0; wv < NWC; ++wv) { p0 += red2[2 * wv]; p1 += red2[2 * wv + 1]; }
+                for (int wv = 0; wv < NWC; ++wv) { p0 += red2[3 * wv]; p1 += red2[3 * wv + 1]; pm = fmaxf(pm, red2[3 * wv + 2]); }
                 float* po = a.part + ((size_t)b * tpw + tx) * 2;
                 po[0] = p0;
                 po[1] = p1;
+                if (a.cmax != nullptr && pm > 0.f) atomicMax(reinterpret_cast<unsigned int*>(a.cmax) + b, __float_as_uint(pm));
             }
         }
         __syncthreads();  // END
@@ -759,21 +779,28 @@ __global__ void logits_kernel(const float* __restrict__ part, const float* __res
 }
 
 // ---------------------------------------------------------------------------------------
-// Fused ensemble post-processing, one workgroup per window (HBM-bound: reads E CAM rows +
-// the aggregate, writes states [+ power, + average CAM]).  Restates, in the reference's
-// order and precisions:
+// Fused ensemble post-processing (HBM-bound: reads E CAM rows + the aggregate once, writes
+// states [+ power, + average CAM]).  Grid = (time tiles of POST_TILE, windows); a workgroup
+// owns one tile of one window, one dword per lane per access (256 contiguous bytes per wave
+// instruction).  Restates, in the reference's order and precisions:
 //   core.py:305      prob += softmax(logits)[1]             (float32 softmax, float64 sum)
 //   core.py:308-317  if argmax==1: c = clip(cam,0); nan/inf->0; if max(c)>0: pred += c/max(c)
 //   core.py:320-324  prob/=E; pred/=E; pred *= round_half_even(prob)
 //   core.py:429-437  ma = convolve(pred, ones(w),'same')/w; s = 2/(1+exp(-ma*x))-1; round(s)
 //   core.py:216-218  power = min(int(state)*p_on, x*scale_mul+scale_add)
+// max(c) per member and window comes from the CAM-head epilogue (cmax, one atomic max per
+// head tile), so the rows are read exactly once; OWN_MAX = true (camal_postprocess on rows
+// the caller brought) scans the window's rows for it instead.
 // ---------------------------------------------------------------------------------------
 #define CAMAL_MAX_MEMBERS 16
 #define POST_TILE 1024
+#define POST_PER_LANE (POST_TILE / 256)
 
 struct PostArgs {
-    const float* cam;      // [E][B][L]
-    const float* logits;   // [E][B][2]
+    const float* cam;      // member e, window b: cam + e*cam_estride + b*L
+    const float* logits;   // logits + e*lg_estride + 2*b
+    const float* cmax;     // cmax + e*cmax_estride + b   (unused when OWN_MAX)
+    size_t cam_estride, lg_estride, cmax_estride;
     const float* x;        // [B][L]
     const double* x64;     // [B][L] or null
     const int8_t* y;       // [B] or null
@@ -785,106 +812,212 @@ struct PostArgs {
     double p_on, scale_mul, scale_add;
 };
 
-__device__ __forceinline__ float clip_cam(float v) {
-    v = v > 0.f ? v : 0.f;           // np.clip(a_min=0); NaN compares false -> 0 (nan_to_num)
-    return isinf(v) ? 0.f : v;       // posinf -> 0
+// np.round(2/(1+exp(-z)) - 1) with z = (sum/w)*x  (core.py:431-437), values -1, -0, +0, 1.
+// The rounded value only depends on which side of +-ln 3 (and of 0) z falls, so the exponential
+// and the two float64 divisions run only where that is in doubt: within 1e-6 of +-ln 3, for
+// 1e-17 <= |z| < 1e-9 (where exp(-z) may or may not round to 1, which decides -0 against +0),
+// and for NaN.  Everywhere else the answer of the full float64 evaluation is implied:
+//   |z| < 1e-17: exp(-z) == 1 -> +0;  else the sign of z, and magnitude 1 iff |z| > ln 3.
+__device__ __forceinline__ double attention_state(double sum, int w, double inv_w, double x) {
+    constexpr double LN3 = 1.0986122886681098;
+    const double zf = (sum * inv_w) * x;  // within a few ulp of (sum / w) * x
+    const double az = fabs(zf);
+    if (az < 1e-17) return 0.0;
+    if (az >= 1e-9 && fabs(az - LN3) > 1e-6) return copysign(az > LN3 ? 1.0 : 0.0, zf);
+    const double z = (sum / (double)w) * x;
+    return rint(2.0 * (1.0 / (1.0 + exp(-z))) - 1.0);
 }
 
+// pred[t] of core.py:308-324 at NS positions of window row `row`: members that voted 'on' add
+// clip(cam)/max(clip(cam)) in member order (float32 sum when the caller's data was float32,
+// float64 otherwise), /E, * vote.  c/max as float32(float64(c) * (1/float64(max))): 53 bits
+// cover the correctly rounded float32 quotient of two float32 numbers.
+template <int NS, bool F64, int MU>
+__device__ __forceinline__ void ensemble_pred(const PostArgs& a, const float* s_max, const double* s_rinv,
+                                              const int* s_lab, size_t row, const unsigned (&off)[NS],
+                                              const bool (&ok)[NS], double vote, double (&out)[NS]) {
+    // off[j]: BYTE offset of the position inside the window row, already clamped into it (a position that
+    // is not wanted still loads a valid address; ok[j] = false zeroes its result).  32-bit byte offsets on a
+    // wave-uniform row base let the loads use the scalar-base addressing form (no 64-bit lane addresses).
+    float accf[NS];
+    double accd[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) { accf[j] = 0.f; accd[j] = 0.0; }
+    // MU members per round: all their loads are in flight before the first is consumed (every round is
+    // one more memory round trip on the workgroup's critical path; the host picks MU);
+    // a member that is off loads nothing and adds an exact +0
+    for (int e0 = 0; e0 < a.E; e0 += MU) {
+        float v[MU][NS];
+        double ri[MU];
+#pragma unroll
+        for (int u = 0; u < MU; ++u) {
+            const int e = e0 + u < a.E ? e0 + u : 0;
+            const bool on = __builtin_amdgcn_readfirstlane((int)(e0 + u < a.E && s_lab[e] && s_max[e] > 0.f));
+            ri[u] = 0.0;
+#pragma unroll
+            for (int j = 0; j < NS; ++j) v[u][j] = 0.f;
+            if (on) {  // wave-uniform
+                ri[u] = s_rinv[e];
+                const char* c = reinterpret_cast<const char*>(a.cam + e * a.cam_estride + row);
+#pragma unroll
+                for (int j = 0; j < NS; ++j) v[u][j] = *reinterpret_cast<const float*>(c + off[j]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < MU; ++u) {
+            if (ri[u] == 0.0) continue;  // wave-uniform: member off
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                const float q = (float)((double)clip_cam(v[u][j]) * ri[u]);
+                if (F64) accd[j] += (double)q;
+                else accf[j] += q;
+            }
+        }
+    }
+    // pred / len(models): float64 division, or the float32 one by the same float64-product argument
+    const double inv_e = 1.0 / (double)a.E;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const double avg = F64 ? accd[j] / (double)a.E : (double)(float)((double)accf[j] * inv_e);
+        out[j] = ok[j] ? avg * vote : 0.0;
+    }
+}
+
+template <bool OWN_MAX, int MU>
 __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
     __shared__ float s_max[CAMAL_MAX_MEMBERS];
+    __shared__ double s_rinv[CAMAL_MAX_MEMBERS];
+    __shared__ float s_p1[CAMAL_MAX_MEMBERS];
     __shared__ int s_lab[CAMAL_MAX_MEMBERS];
-    __shared__ double s_prob;
     __shared__ float s_red[4];
+    __shared__ int s_y;
     __shared__ double s_pred[POST_TILE + 64];
-    const int b = blockIdx.x, L = a.L, E = a.E;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y, c0 = blockIdx.x * POST_TILE, L = a.L, E = a.E;
+    const int tid = threadIdx.x;
+    const int n = min(POST_TILE, L - c0);
+    const size_t row = (size_t)b * L;
 
-    if (threadIdx.x == 0) {
-        double psum = 0.0;
-        bool skip = false;
-        if (a.y) skip = a.y[b] < 1;
-        for (int e = 0; e < E; ++e) {
-            const float* lg = a.logits + ((size_t)e * a.B + b) * 2;
-            float l0 = lg[0], l1 = lg[1];
-            float m = fmaxf(l0, l1);
-            float e0 = expf(l0 - m), e1 = expf(l1 - m);
-            float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
-            int lab = p1 > p0 ? 1 : 0;
-            if (e == 0 && !a.y && a.gate_mode == 1) skip = lab < 1;
-            s_lab[e] = lab;
-            psum += (double)p1;
-        }
-        if (skip) {
-            psum = 0.0;
-            for (int e = 0; e < E; ++e) s_lab[e] = 0;
-        }
-        s_prob = psum / (double)E;
-    }
-    __syncthreads();
-    const double prob = s_prob;
-    const double vote = rint(prob);  // np.round: half to even
-    if (threadIdx.x == 0) a.prob_out[b] = prob;
-
-    // per-member max of the clipped CAM (only members that voted 'on', only if the window passes)
-    for (int e = 0; e < E; ++e) {
-        if (!s_lab[e] || vote == 0.0) { if (threadIdx.x == 0) s_max[e] = 0.f; continue; }
-        const float* c = a.cam + ((size_t)e * a.B + b) * L;
-        float m = 0.f;
-        for (int t = threadIdx.x; t < L; t += 256) m = fmaxf(m, clip_cam(c[t]));
+    // window header, one lane per member: float32 softmax, label, row maximum.  Its loads (small, still
+    // in L2 from the kernels that wrote them) are issued FIRST and unconditionally; the loads of the
+    // aggregate (HBM; needed whatever the vote) follow, so the header only waits for its own data.
+    // Raw loads only up here: a conversion or a branch in between makes the loads wait in turn.
+    const int he = min(tid, E - 1);
+    const float* lg = a.logits + he * a.lg_estride + 2 * (size_t)b;
+    const float l0 = lg[0], l1 = lg[1];
+    const float cm = OWN_MAX ? 0.f : a.cmax[he * a.cmax_estride + b];
+    const int yv = *(a.y ? a.y + b : reinterpret_cast<const int8_t*>(lg));  // always a valid address
+    __builtin_amdgcn_sched_barrier(0);  // keep the header loads ahead of the aggregate's in the queue
+    float xf[POST_PER_LANE];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        __syncthreads();
-        if (lane == 0) s_red[wave] = m;
-        __syncthreads();
-        if (threadIdx.x == 0) s_max[e] = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    for (int j = 0; j < POST_PER_LANE; ++j) xf[j] = (a.x + row)[(unsigned)(c0 + min(tid + 256 * j, n - 1))];
+    __builtin_amdgcn_sched_barrier(0);
+    if (tid < E) {
+        const float m = fmaxf(l0, l1);
+        const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+        const float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
+        s_p1[tid] = p1;
+        s_lab[tid] = p1 > p0 ? 1 : 0;
+        s_max[tid] = cm;
+        s_rinv[tid] = cm > 0.f ? 1.0 / (double)cm : 0.0;
+        if (tid == 0) s_y = yv;
     }
     __syncthreads();
+    // every lane repeats the (ordered, float64) member sum: broadcast LDS reads, no second barrier
+    bool skip = false;
+    if (a.y) skip = s_y < 1;
+    else if (a.gate_mode == 1) skip = s_lab[0] < 1;
+    double psum = 0.0;
+    for (int e = 0; e < E; ++e) psum += (double)s_p1[e];
+    const double prob = skip ? 0.0 : psum / (double)E;
+    const double vote = rint(prob);  // np.round: half to even
+    if (tid == 0 && blockIdx.x == 0) a.prob_out[b] = prob;
+    const bool pass = !skip && vote != 0.0;  // else pred == 0 on the whole window
 
-    // np.convolve(x, ones(w), 'same')[t] = sum_{m = t + hi - w + 1 .. t + hi} x[m], hi = (w-1)/2
     const int w = a.w_ma, hi = (w - 1) / 2, lo = hi - w + 1;  // lo <= 0
-    const float* xb = a.x + (size_t)b * L;
-    for (int c0 = 0; c0 < L; c0 += POST_TILE) {
-        const int n = min(POST_TILE, L - c0);
-        // pred for positions [c0 + lo, c0 + n + hi)
-        for (int i = threadIdx.x; i < n + hi - lo; i += 256) {
-            const int t = c0 + lo + i;
-            double pv = 0.0;
-            if (t >= 0 && t < L && vote != 0.0) {
-                if (a.pred_f64) {
-                    double acc = 0.0;
-                    for (int e = 0; e < E; ++e)
-                        if (s_max[e] > 0.f) acc += (double)(clip_cam(a.cam[((size_t)e * a.B + b) * L + t]) / s_max[e]);
-                    pv = acc / (double)E;
-                } else {
-                    float acc = 0.f;
-                    for (int e = 0; e < E; ++e)
-                        if (s_max[e] > 0.f) acc += clip_cam(a.cam[((size_t)e * a.B + b) * L + t]) / s_max[e];
-                    pv = (double)(acc / (float)E);
+    const double inv_w = 1.0 / (double)w;
+
+    double xd[POST_PER_LANE];
+    if (a.x64) {
+#pragma unroll
+        for (int j = 0; j < POST_PER_LANE; ++j) xd[j] = (a.x64 + row)[(unsigned)(c0 + min(tid + 256 * j, n - 1))];
+    }
+
+    if (pass) {
+        if (OWN_MAX) {
+            const int lane = tid & 63, wave = tid >> 6;
+            for (int e = 0; e < E; ++e) {
+                float m = 0.f;
+                if (s_lab[e]) {
+                    const float* c = a.cam + e * a.cam_estride + row;
+                    for (int t = tid; t < L; t += 256) m = fmaxf(m, clip_cam(c[t]));
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
                 }
-                pv = pv * vote;
+                __syncthreads();
+                if (lane == 0) s_red[wave] = m;
+                __syncthreads();
+                if (tid == 0) {
+                    const float mm = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+                    s_max[e] = mm;
+                    s_rinv[e] = mm > 0.f ? 1.0 / (double)mm : 0.0;
+                }
             }
-            s_pred[i] = pv;
+            __syncthreads();
+        }
+
+        // ---- ensemble-averaged, vote-gated CAM of the tile -> LDS slot (position - c0 - lo)
+        // np.convolve(p, ones(w), 'same')[t] = sum_{m = t + lo .. t + hi} p[m]: the tile needs pred on
+        // [c0 + lo, c0 + n + hi)
+        {
+            unsigned off[POST_PER_LANE];
+            bool ok[POST_PER_LANE];
+            double pr[POST_PER_LANE];
+#pragma unroll
+            for (int j = 0; j < POST_PER_LANE; ++j) {
+                const int i = tid + 256 * j;
+                off[j] = 4u * (unsigned)(c0 + min(i, n - 1));
+                ok[j] = i < n;
+            }
+            if (a.pred_f64) ensemble_pred<POST_PER_LANE, true, MU>(a, s_max, s_rinv, s_lab, row, off, ok, vote, pr);
+            else ensemble_pred<POST_PER_LANE, false, MU>(a, s_max, s_rinv, s_lab, row, off, ok, vote, pr);
+#pragma unroll
+            for (int j = 0; j < POST_PER_LANE; ++j) {
+                const int i = tid + 256 * j;
+                if (i < n) s_pred[i - lo] = pr[j];
+            }
+        }
+        if (tid < w - 1) {  // halo: -lo positions before the tile, hi after it (zero outside the window)
+            const bool left = tid < -lo;
+            const int t = left ? c0 + lo + tid : c0 + n + (tid + lo);
+            unsigned off[1] = {4u * (unsigned)min(max(t, 0), L - 1)};
+            bool ok[1] = {t >= 0 && t < L};
+            double pr[1];
+            if (a.pred_f64) ensemble_pred<1, true, MU>(a, s_max, s_rinv, s_lab, row, off, ok, vote, pr);
+            else ensemble_pred<1, false, MU>(a, s_max, s_rinv, s_lab, row, off, ok, vote, pr);
+            s_pred[left ? tid : n + tid] = pr[0];
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += 256) {
-            const int t = c0 + i;
-            double sum = 0.0;
+    }
+
+    // ---- moving average, rectified sigmoid of (ma * aggregate), round, power
+#pragma unroll
+    for (int j = 0; j < POST_PER_LANE; ++j) {
+        const int i = tid + 256 * j;
+        if (i >= n) continue;
+        const unsigned o = (unsigned)(c0 + i);
+        double sum = 0.0;
+        if (pass)
             for (int m = 0; m < w; ++m) sum += s_pred[i + m];
-            const double ma = sum / (double)w;
-            const double xv = a.x64 ? a.x64[(size_t)b * L + t] : (double)xb[t];
-            const double z = ma * xv;
-            const double sg = 2.0 * (1.0 / (1.0 + exp(-z))) - 1.0;
-            const double st = rint(sg);
-            a.state_out[(size_t)b * L + t] = (float)st;
-            if (a.avg_out) a.avg_out[(size_t)b * L + t] = (float)s_pred[i - lo];
-            if (a.power_out) {
-                const double agg = xv * a.scale_mul + a.scale_add;
-                double yh = (double)(long long)st * a.p_on;
-                if (yh > agg) yh = agg;
-                a.power_out[(size_t)b * L + t] = (float)yh;
-            }
+        const double xv = a.x64 ? xd[j] : (double)xf[j];
+        const double st = attention_state(sum, w, inv_w, xv);
+        (a.state_out + row)[o] = (float)st;
+        if (a.avg_out) (a.avg_out + row)[o] = pass ? (float)s_pred[i - lo] : 0.f;
+        if (a.power_out) {
+            const double agg = xv * a.scale_mul + a.scale_add;
+            double yh = (double)(int)st * a.p_on;  // astype(int) of -1, -0, 0, 1
+            if (yh > agg) yh = agg;
+            (a.power_out + row)[o] = (float)yh;
         }
-        __syncthreads();
     }
 }
 
@@ -900,8 +1033,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const double* __restrict
     double sum = 0.0;
     for (int m = t + lo; m <= t + hi; ++m)
         if (m >= 0 && m < L) sum += sb[m];
-    const double z = (sum / (double)w) * x[(size_t)b * L + t];
-    out[(size_t)b * L + t] = rint(2.0 * (1.0 / (1.0 + exp(-z))) - 1.0);
+    out[(size_t)b * L + t] = attention_state(sum, w, 1.0 / (double)w, x[(size_t)b * L + t]);
 }
 
 }  // namespace camal
