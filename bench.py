@@ -14,6 +14,8 @@ Workloads (BASELINE.json `configs`):
   ensemble_bf16 configs[2]: 5 members k=5,7,9,15,25, bf16 MFMA, REFIT-shaped day windows (L=1440)
   ensemble_fp32 same ensemble in fp32
   long_bf16     configs[4]: ensemble, L=10080 week windows, + power estimate
+  train_fp32    configs[3]: ensemble training step (forward + backward + AdamW for each of the 5 members)
+                on IDEAL-shaped windows (128 x 510 per GPU), gradients all-reduced over RCCL when N > 1
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -33,7 +35,9 @@ WORKLOADS = {
     "ensemble_bf16": dict(kernels=[5, 7, 9, 15, 25], B=4096, L=1440, precision="bf16", shape="refit"),
     "ensemble_fp32": dict(kernels=[5, 7, 9, 15, 25], B=1024, L=1024, precision="fp32", shape="ukdale"),
     "long_bf16": dict(kernels=[5, 7, 9, 15, 25], B=512, L=10080, precision="bf16", shape="refit"),
+    "train_fp32": dict(kernels=[5, 7, 9, 15, 25], B=128, L=510, precision="fp32", shape="ideal"),
 }
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md "HBM": 8 TB/s spec (about 6.3 TB/s achievable)
 # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}
 
@@ -49,6 +53,77 @@ def make_windows(shape, n, length, seed):
     if shape == "refit":
         return synth.refit_windows(n, length, seed=seed)
     return synth.ukdale_windows(n, length, seed=seed)
+
+
+def measured_traffic(workload, kernel_class):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json, made by
+    tools/traffic.py from FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE); None if not collected."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f)[workload][kernel_class]["bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def train_main(args, wl, rank, local_rank, world, dev, dist):
+    """configs[3]: one step = forward + backward + AdamW of every ensemble member on this rank's batch;
+    with N > 1 each member's flat gradient bucket is all-reduced (mean) over RCCL before its update."""
+    from camal_amd import synth
+    from camal_amd.resnet import CamALResNet
+    from camal_amd.trainer import TrainEngine
+    B, L, ks = wl["B"], wl["L"], wl["kernels"]
+    x_host, y_host = synth.ideal_windows(B, L, seed=2000 + rank)
+    x = torch.from_numpy(x_host).to(dev)
+    y = torch.from_numpy(y_host).to(dev)
+    engines = []
+    for k in ks:
+        torch.manual_seed(k)  # same initial weights on every rank (DDP starts from one model)
+        m = CamALResNet(kernel_size=k)
+        engines.append(TrainEngine(m, dev, B, L))
+
+    def step():
+        for e in engines:
+            e.forward_backward(x, y)
+            e.optimizer_step(1e-3, 1e-2)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        # forward conv MACs x3 (forward, data gradient, weight gradient); the stem has no data gradient
+        flops_step = 3 * 2.0 * L * B * sum(conv_macs_per_timestep(k) for k in ks)
+        achieved = flops_step * args.steps / dt / 1e12
+        res = {
+            "metric": "windows/sec (train: forward+backward+AdamW, all members)",
+            "value": world * B * args.steps / dt, "unit": "windows/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"train_fp32: E={len(ks)} k={ks} B={B}/GPU L={L} fwd+bwd+AdamW per member",
+                       "windows_per_gpu_per_step": B, "window_len": L, "kernel_sizes": ks,
+                       "inputs": "resident in HBM",
+                       "parallelism": f"data-parallel x{world}, one all-reduce of each member's gradient bucket"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_TFLOPS["fp32"], "traffic": None,
+                         "kernel": "whole step (wall clock): conv forward + dgrad + wgrad MFMA kernels, BN/loss/AdamW",
+                         "alg_flops_per_step": flops_step},
+            "sanity": {"loss": [float(e.loss.item()) for e in engines]},
+        }
+        print(json.dumps(res), flush=True)
 
 
 def cpu_baseline(sds, x, budget_s=15.0):
@@ -97,6 +172,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(dev))
 
+    if args.workload == "train_fp32":
+        train_main(args, wl, rank, local_rank, world, dev, dist)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     from camal_amd.calibrate import calibrated_state_dicts
     from camal_amd.engine import Ensemble
 
@@ -142,6 +224,8 @@ def main():
         flops_step = 2.0 * L * B * sum(conv_macs_per_timestep(k) for k in ks)
         achieved = flops_step * args.steps / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         peak = PEAK_TFLOPS[wl["precision"]]
+        post_bytes_step = 4.0 * B * L * (len(ks) * vote_frac + 3)
+        post_gbs = post_bytes_step * args.steps / (prof["post"][1] * 1e-3) / 1e9 if prof["post"][1] > 0 else 0.0
         res = {
             "metric": "windows/sec (detect+CAM localize)",
             "value": world * B * args.steps / dt,
@@ -156,10 +240,20 @@ def main():
                        "inputs": "resident in HBM", "parallelism": f"window-sharded x{world}, no collective"},
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                "frac": achieved / peak, "traffic": None,
-                "kernel": "camal::conv_kernel<*> (implicit-GEMM Conv1d+BN+ReLU, all MFMA layers)",
+                "frac": achieved / peak, "traffic": measured_traffic(args.workload, "conv"),
+                "kernel": "camal::conv_kernel<*> + camal::block_kernel<*> (implicit-GEMM Conv1d+BN+ReLU[+skip][+CAM head], "
+                          "every MFMA launch of the step)",
                 "launches": conv_n, "avg_launch_ms": conv_ms / max(conv_n, 1),
-                "alg_flops_per_step": flops_step,
+                "alg_flops_per_step": flops_step, "alg_flops_per_launch": flops_step * args.steps / max(conv_n, 1),
+            },
+            # the fused CAM post-processing kernel against the HBM roofline: bytes that must move given the
+            # votes = 4 B x (E CAM rows of the windows voted on + aggregate + state + power) per timestamp
+            "roofline_post": {
+                "bound": "hbm", "achieved": post_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": post_gbs / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, "post"),
+                "kernel": "camal::post_kernel (ensemble average + vote gate + moving average + states + power)",
+                "launches": prof["post"][0], "avg_launch_ms": prof["post"][1] / max(prof["post"][0], 1),
+                "alg_bytes_per_launch": post_bytes_step * args.steps / max(prof["post"][0], 1),
             },
             "kernel_ms_per_step": {k: v[1] / args.steps for k, v in prof.items()},
             "sanity": {"state_on_fraction": on_frac, "windows_voted_on": vote_frac},
