@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256) void stem_train_kernel(const float* __restrict
 // Batch statistics over the N = B*L rows of z [N][C] (biased variance for the normalisation,
 // unbiased for the running update, momentum 0.1 — torch.nn.BatchNorm1d as used at
 // camal_resnet.py:53,84).  Stage 1: per-block partial (sum, sum of squares) in double.
-#define BN_ROWS_PER_BLOCK 256
+#define BN_ROWS_PER_BLOCK 64
+#define BN_FINAL_THREADS 1024
 
 template <int C>
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ z, int N,
@@ -112,14 +113,38 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     }
 }
 
+// Stage 2, one workgroup: BN_FINAL_THREADS / C lanes per channel each sum a fixed strided subset of the
+// partials, then a fixed-order combine through LDS (deterministic, and short dependent chains: a single
+// lane per channel walking every partial was 60 us of pure load latency per BatchNorm).
 template <int C>
-__global__ void bn_stats_final_kernel(const double* __restrict__ partial, int nblocks, int N, float eps, float momentum,
-                                      float* __restrict__ mean, float* __restrict__ invstd,
-                                      float* __restrict__ running_mean, float* __restrict__ running_var) {
-    const int c = threadIdx.x;
-    if (c >= C) return;
+__device__ __forceinline__ void bn_final_reduce(const double* __restrict__ partial, int nblocks, double& a, double& b) {
+    constexpr int G = BN_FINAL_THREADS / C;
+    __shared__ double sh[BN_FINAL_THREADS][2];
+    const int c = threadIdx.x % C, g = threadIdx.x / C;
     double s = 0.0, ss = 0.0;
-    for (int g = 0; g < nblocks; ++g) { s += partial[((size_t)g * C + c) * 2]; ss += partial[((size_t)g * C + c) * 2 + 1]; }
+#pragma unroll 4
+    for (int i = g; i < nblocks; i += G) {
+        s += partial[((size_t)i * C + c) * 2];
+        ss += partial[((size_t)i * C + c) * 2 + 1];
+    }
+    sh[threadIdx.x][0] = s;
+    sh[threadIdx.x][1] = ss;
+    __syncthreads();
+    a = 0.0; b = 0.0;
+    if (g == 0) {
+#pragma unroll
+        for (int k = 0; k < G; ++k) { a += sh[k * C + c][0]; b += sh[k * C + c][1]; }
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(BN_FINAL_THREADS) void bn_stats_final_kernel(
+    const double* __restrict__ partial, int nblocks, int N, float eps, float momentum, float* __restrict__ mean,
+    float* __restrict__ invstd, float* __restrict__ running_mean, float* __restrict__ running_var) {
+    double s, ss;
+    bn_final_reduce<C>(partial, nblocks, s, ss);
+    if (threadIdx.x >= C) return;
+    const int c = threadIdx.x;
     const double m = s / N;
     double var = ss / N - m * m;
     var = var > 0.0 ? var : 0.0;
@@ -193,12 +218,14 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 }
 
 template <int C>
-__global__ void bn_bwd_final_kernel(const double* __restrict__ partial, int nblocks, float* __restrict__ s1,
-                                    float* __restrict__ s2, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+__global__ __launch_bounds__(BN_FINAL_THREADS) void bn_bwd_final_kernel(const double* __restrict__ partial, int nblocks,
+                                                                        float* __restrict__ s1, float* __restrict__ s2,
+                                                                        float* __restrict__ dgamma,
+                                                                        float* __restrict__ dbeta) {
+    double a, b;
+    bn_final_reduce<C>(partial, nblocks, a, b);
+    if (threadIdx.x >= C) return;
     const int c = threadIdx.x;
-    if (c >= C) return;
-    double a = 0.0, b = 0.0;
-    for (int g = 0; g < nblocks; ++g) { a += partial[((size_t)g * C + c) * 2]; b += partial[((size_t)g * C + c) * 2 + 1]; }
     s1[c] = (float)a;
     s2[c] = (float)b;
     dbeta[c] = (float)a;
@@ -241,7 +268,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 // ---- pooled head + cross-entropy (camal_resnet.py:23, torch_trainer.py:288-296) -------------------
 // One workgroup per window: pooled = mean_t F; logits = W pooled + b; softmax; CE; argmax;
 // dlogits = (p - onehot) / B; dpool = W^T dlogits.
-__global__ __launch_bounds__(256) void head_loss_kernel(const float* __restrict__ feat /*[B][L][128]*/,
+#define HEAD_LOSS_THREADS 1024
+__global__ __launch_bounds__(HEAD_LOSS_THREADS) void head_loss_kernel(const float* __restrict__ feat /*[B][L][128]*/,
                                                         const float* __restrict__ wfc, const float* __restrict__ bfc,
                                                         const int* __restrict__ labels, int B, int L,
                                                         float* __restrict__ pooled /*[B][128]*/,
@@ -249,20 +277,24 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const float* __restrict_
                                                         float* __restrict__ logits /*[B][2]*/,
                                                         float* __restrict__ dlogits /*[B][2]*/,
                                                         float* __restrict__ loss /*[B]*/, int* __restrict__ correct) {
-    __shared__ float sp[256];
+    __shared__ float sp[HEAD_LOSS_THREADS];
     __shared__ float sl[4];
-    const int b = blockIdx.x, c = threadIdx.x & 127, half = threadIdx.x >> 7;
+    constexpr int TG = HEAD_LOSS_THREADS / 128;  // time groups per channel
+    const int b = blockIdx.x, c = threadIdx.x & 127, tg = threadIdx.x >> 7;
     const float* f = feat + (size_t)b * L * 128;
     float s = 0.f;
-    for (int t = half; t < L; t += 2) s += f[(size_t)t * 128 + c];
+#pragma unroll 4
+    for (int t = tg; t < L; t += TG) s += f[(size_t)t * 128 + c];
     sp[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x < 128) {
-        const float p = (sp[c] + sp[c + 128]) / (float)L;
-        sp[c] = p;
-        pooled[(size_t)b * 128 + c] = p;
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < TG; ++k) a += sp[c + 128 * k];
+        sp[c] = a / (float)L;
     }
     __syncthreads();
+    if (threadIdx.x < 128) pooled[(size_t)b * 128 + c] = sp[c];
     if (threadIdx.x < 2) {
         float a = 0.f;
         for (int k = 0; k < 128; ++k) a = fmaf(wfc[threadIdx.x * 128 + k], sp[k], a);
