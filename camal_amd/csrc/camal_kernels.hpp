@@ -24,6 +24,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 template <typename DT> struct Elem;
 template <> struct Elem<float> { static constexpr int PER_CHUNK = 4; static constexpr int K_PER_PAIR = 8; };
 template <> struct Elem<__bf16> { static constexpr int PER_CHUNK = 8; static constexpr int K_PER_PAIR = 16; };
@@ -142,25 +144,40 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+// Weight loads of the K loop, hidden from hipcc (guide §5.7 item 1, form (ii)): wave-uniform base in
+// scalar registers + the lane's 32-bit byte offset, and the waits counted by hand.  hipcc's own
+// bookkeeping put a vmcnt(0) at the head of the tap loop (the ring's prologue order and a spilled 64-bit
+// lane pointer reloaded there), which drained the ring once per tap, and kept one 64-bit lane address
+// per layer alive (spills under the 168-register cap).  A destination is valid only after w_wait.
+__device__ __forceinline__ void w_load(u32x4& dst, const void* sbase, unsigned lane_off) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(lane_off), "s"(sbase) : "memory");
+}
+template <int N> __device__ __forceinline__ void w_wait(u32x4& r) {
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(N) : "memory");
+}
+
 // K loop of one conv layer for one wave: acc[nt] += sum over taps and chunk pairs of
 // A (weights, 32 out-channels, streamed from L2 in packed order through a register ring that keeps
 // AR-1 loads in flight) x B (activations read from the LDS tile at row R0 + tap + 32 nt, one chunk
 // pair ahead).  Software-pipelined by hand; ring slots are static after unrolling.
+// wp is WAVE-UNIFORM (the lane's 16 bytes are added inside).  No other vector-memory operation may be
+// issued by the caller's wave between entry and exit: the ring's waits count from the youngest load.
 template <typename DT, int CIN, int NT, int MTW = 1>
 __device__ __forceinline__ void mma_layer(const char* buf, int R0, int ks, const uint4* wp, f32x16 (&acc)[MTW][NT]) {
     // MTW = out-channel tiles per wave (consecutive in the packed weights: stride ks*NCP*64 uint4)
     constexpr int RB = CIN * (int)sizeof(DT), CPR = RB / 16, NCP = CIN / Elem<DT>::K_PER_PAIR;
     constexpr int AR = sizeof(DT) == 4 ? 2 : 4;
     static_assert(NCP % AR == 0 && NCP % 2 == 0, "ring sizes must divide the chunk pairs per tap");
+    const unsigned loff = (threadIdx.x & 63) * 16;
     const int h = (threadIdx.x & 63) >> 5;
     const int total = ks * NCP;
     const size_t mstride = (size_t)total * 64;
-    uint4 a[AR][MTW];
+    u32x4 a[AR][MTW];
     uint4 bq[2][NT];
 #pragma unroll
     for (int d = 0; d < AR - 1; ++d)
 #pragma unroll
-        for (int m = 0; m < MTW; ++m) a[d][m] = wp[m * mstride + (size_t)(d < total ? d : total - 1) * 64];
+        for (int m = 0; m < MTW; ++m) w_load(a[d][m], wp + m * mstride + (size_t)(d < total ? d : total - 1) * 64, loff);
     {
         const char* rowp = buf + R0 * RB;
         const int col = (h ^ swz<CPR>(R0)) << 4;
@@ -176,9 +193,9 @@ __device__ __forceinline__ void mma_layer(const char* buf, int R0, int ks, const
 #pragma unroll
         for (int cp = 0; cp < NCP; ++cp) {
             int idx = j * NCP + cp + (AR - 1);
-            idx = idx < total ? idx : total - 1;
+            idx = idx < total ? idx : total - 1;  // past the end: a repeated load keeps the wait counts uniform
 #pragma unroll
-            for (int m = 0; m < MTW; ++m) a[(cp + AR - 1) % AR][m] = wp[m * mstride + (size_t)idx * 64];
+            for (int m = 0; m < MTW; ++m) w_load(a[(cp + AR - 1) % AR][m], wp + m * mstride + (size_t)idx * 64, loff);
             const char* rp = cp + 1 < NCP ? rowp : rowpn;
             const int col = cp + 1 < NCP ? ((2 * (cp + 1) + h) ^ s) << 4 : (h ^ sn) << 4;
             // issue order pinned by hand: each LDS read of the NEXT step's fragment rides in the shadow of
@@ -197,6 +214,9 @@ __device__ __forceinline__ void mma_layer(const char* buf, int R0, int ks, const
                         for (int nt = 4; nt < NT; ++nt)
                             bq[(cp + 1) & 1][nt] = *reinterpret_cast<const uint4*>(rp + nt * 32 * RB + col);
                     __builtin_amdgcn_sched_barrier(0);
+                    if (ks4 == 0)  // this step's weights: all but the AR-1 younger steps' loads have landed
+#pragma unroll
+                        for (int m = 0; m < MTW; ++m) w_wait<(AR - 1) * MTW>(a[cp % AR][m]);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         const float* bf = reinterpret_cast<const float*>(&bq[cp & 1][nt]);
@@ -213,13 +233,22 @@ __device__ __forceinline__ void mma_layer(const char* buf, int R0, int ks, const
                 for (int nt = 0; nt < NT; ++nt) {
                     bq[(cp + 1) & 1][nt] = *reinterpret_cast<const uint4*>(rp + nt * 32 * RB + col);
                     __builtin_amdgcn_sched_barrier(0);
+                    if (nt == 0)
 #pragma unroll
-                    for (int m = 0; m < MTW; ++m) mma_chunk(a[cp % AR][m], bq[cp & 1][nt], acc[m][nt], DT());
+                        for (int m = 0; m < MTW; ++m) w_wait<(AR - 1) * MTW>(a[cp % AR][m]);
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m)
+                        mma_chunk(*reinterpret_cast<const uint4*>(&a[cp % AR][m]), bq[cp & 1][nt], acc[m][nt], DT());
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
     }
+    // the repeated tail loads are still in flight: nothing may reuse their registers before they land
+#pragma unroll
+    for (int d = 0; d < AR; ++d)
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) w_wait<0>(a[d][m]);
 }
 
 // core.py:308-310 on one CAM value: clip below at 0, NaN and +inf -> 0
@@ -306,7 +335,7 @@ __global__ __launch_bounds__((NWC + 1) * 64) void conv_kernel(const DT* __restri
     // ---------------------------------- compute waves --------------------------------------
     const int mt = wave % MT, ng = wave / MT;
     const int r = lane & 31, h = lane >> 5;
-    const uint4* wp = wpack + (size_t)mt * ks * NCP * 64 + lane;
+    const uint4* wp = wpack + (size_t)mt * ks * NCP * 64;  // wave-uniform; mma_layer adds the lane
     const int R0 = ng * NT * 32 + r;
 
     float bv[4][4];
@@ -592,9 +621,10 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
     const int r = lane & 31, h = lane >> 5;
     const int col0 = ng * NT * 32 + r;  // this lane's first column
     constexpr int NCPI = CIN / Elem<DT>::K_PER_PAIR, NCPA = 128 / Elem<DT>::K_PER_PAIR;
-    const uint4* w1 = a.w1 + (size_t)mt0 * ks1 * NCPI * 64 + lane;
-    const uint4* w2 = a.w2 + (size_t)mt0 * 7 * NCPA * 64 + lane;
-    const uint4* w3 = a.w3 + (size_t)mt0 * 3 * NCPA * 64 + lane;
+    // wave-uniform weight bases; mma_layer adds the lane
+    const uint4* w1 = a.w1 + (size_t)mt0 * ks1 * NCPI * 64;
+    const uint4* w2 = a.w2 + (size_t)mt0 * 7 * NCPA * 64;
+    const uint4* w3 = a.w3 + (size_t)mt0 * 3 * NCPA * 64;
     auto load_bias = [&](const float* bp, int mt, float (&bv)[4][4]) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) load4(bp + 32 * mt + 8 * g + 4 * h, bv[g]);
@@ -663,7 +693,7 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
             }
             if constexpr (HAS_RES) {
                 __syncthreads();  // BR: centre rows of X landed in Q + xb
-                const uint4* wr = a.wr + (size_t)mt0 * NCPI * 64 + lane;
+                const uint4* wr = a.wr + (size_t)mt0 * NCPI * 64;
                 mma_layer<DT, CIN, NT, MTW>(Q + xb, col0, 1, wr, acc);
             }
             DT* outp = reinterpret_cast<DT*>(a.out);
