@@ -91,6 +91,7 @@ struct camal_ctx {
     int num_cu = 256;
     size_t lds_per_cu = 160 * 1024;
     int fused = 1;  // blocks 2 and 3 as fused-block kernels (block_kernel); 0: one conv_kernel per layer
+    int fused_block1 = 1;  // with fused: block 1 as block1_kernel (env CAMAL_FUSED_BLOCK1=0: stem + two conv_kernels)
     std::vector<Member> m;
     std::vector<void*> owned;  // device allocations freed in destroy
     // workspace
@@ -360,21 +361,55 @@ int launch_block(camal_ctx* c, hipStream_t s, const Layer& l1, const Layer& l2, 
     return fail(CAMAL_ERR_ARG, "kernel size too large for the fused block tile");
 }
 
+// fused block 1: x [BC][L] -> block output [BC][L][64]
+template <typename DT>
+int launch_block1(camal_ctx* c, hipStream_t s, const Member& m, const float* x, void* out, int BC, int L) {
+    constexpr int NTB = 2;
+    using G = Block1Geom<DT, NTB>;
+    auto kern = block1_kernel<DT, NTB>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
+        attr_set = true;
+    }
+    Block1Args a;
+    a.x = x; a.out = out;
+    a.w2 = (const uint4*)m.conv[0].wpack; a.w3 = (const uint4*)m.conv[1].wpack;
+    a.b2 = m.conv[0].bias; a.b3 = m.conv[1].bias;
+    a.L = L; a.ks1 = m.k;
+    a.tiles_per_window = (L + G::T - 1) / G::T;
+    const long long total = (long long)a.tiles_per_window * BC;
+    if (total > 0x7fffffffLL) return fail(CAMAL_ERR_ARG, "too many tiles in one pass");
+    a.total_tiles = (int)total;
+    const int per_cu = std::max(1, (int)(c->lds_per_cu / G::LDS_BYTES));
+    const int grid = (int)std::min<long long>(total, (long long)c->num_cu * per_cu);
+    ProfScope ps(c, s, 1);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(G::THREADS), G::LDS_BYTES, s, a, m.stem_w, m.stem_b, m.res1_w, m.res1_b);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // One member's conv stack on BC windows: x -> cam row 1 [BC][L] + pooled partials [BC][ntiles][2]
 template <typename DT>
 int run_member(camal_ctx* c, hipStream_t s, const Member& m, const float* x, int BC, int L, const Workspace& w,
                float* cam, float* part, float* cmax) {
-    {
-        ProfScope ps(c, s, 0);
-        hipLaunchKernelGGL(stem_kernel<DT>, dim3((L + 63) / 64, BC), dim3(256), 0, s, x, m.stem_w, m.stem_b, m.res1_w,
-                           m.res1_b, (DT*)w.a1, (DT*)w.r1, L, m.k);
-        HIP_TRY(hipGetLastError());
-    }
     int r;
-    // block 1: ConvBlock(7), ConvBlock(3) + residual (camal_resnet.py:35-38,56-58)
-    if ((r = launch_conv<DT, C1, C1, true, false, false>(c, s, m.conv[0], w.a1, nullptr, w.b1, nullptr, nullptr, nullptr, BC, L))) return r;
-    if ((r = launch_conv<DT, C1, C1, true, true, false>(c, s, m.conv[1], w.b1, w.r1, w.a1, nullptr, nullptr, nullptr, BC, L))) return r;
-    if (c->fused && fused_fits(c, m.k)) {
+    const bool fused = c->fused && fused_fits(c, m.k);
+    if (fused && c->fused_block1) {
+        // block 1 in one launch: x in, 64-channel block output out
+        if ((r = launch_block1<DT>(c, s, m, x, w.a1, BC, L))) return r;
+    } else {
+        {
+            ProfScope ps(c, s, 0);
+            hipLaunchKernelGGL(stem_kernel<DT>, dim3((L + 63) / 64, BC), dim3(256), 0, s, x, m.stem_w, m.stem_b, m.res1_w,
+                               m.res1_b, (DT*)w.a1, (DT*)w.r1, L, m.k);
+            HIP_TRY(hipGetLastError());
+        }
+        // block 1: ConvBlock(7), ConvBlock(3) + residual (camal_resnet.py:35-38,56-58)
+        if ((r = launch_conv<DT, C1, C1, true, false, false>(c, s, m.conv[0], w.a1, nullptr, w.b1, nullptr, nullptr, nullptr, BC, L))) return r;
+        if ((r = launch_conv<DT, C1, C1, true, true, false>(c, s, m.conv[1], w.b1, w.r1, w.a1, nullptr, nullptr, nullptr, BC, L))) return r;
+    }
+    if (fused) {
         // blocks 2 and 3: one fused kernel each (three ConvBlocks through LDS)
         if ((r = launch_block<DT, C1, true, false>(c, s, m.conv[2], m.conv[3], m.conv[4], &m.res2, w.a1, w.a2, nullptr, nullptr, nullptr, BC, L))) return r;
         if ((r = launch_block<DT, C2, false, true>(c, s, m.conv[5], m.conv[6], m.conv[7], nullptr, w.a2, nullptr, m.wfc, cam, part, BC, L, cmax))) return r;
@@ -460,6 +495,7 @@ int camal_create(int device_id, int n_members, const int* kernel_sizes, int prec
     // bound (bf16), a 6 % loss of MFMA work where it is already MFMA-bound (fp32, 128-column tiles)
     c->fused = precision == CAMAL_BF16;
     if (const char* e = getenv("CAMAL_FUSED")) c->fused = atoi(e) != 0;
+    if (const char* e = getenv("CAMAL_FUSED_BLOCK1")) c->fused_block1 = atoi(e) != 0;
     if (const char* e = getenv("CAMAL_POST_WINDOWS")) c->post_windows = std::max(1, atoi(e));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;

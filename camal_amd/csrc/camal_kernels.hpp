@@ -166,7 +166,14 @@ template <typename DT, int CIN, int NT, int MTW = 1>
 __device__ __forceinline__ void mma_layer(const char* buf, int R0, int ks, const uint4* wp, f32x16 (&acc)[MTW][NT]) {
     // MTW = out-channel tiles per wave (consecutive in the packed weights: stride ks*NCP*64 uint4)
     constexpr int RB = CIN * (int)sizeof(DT), CPR = RB / 16, NCP = CIN / Elem<DT>::K_PER_PAIR;
-    constexpr int AR = sizeof(DT) == 4 ? 2 : 4;
+#ifndef CAMAL_AR_F32
+#define CAMAL_AR_F32 2
+#endif
+#ifndef CAMAL_AR_BF16
+#define CAMAL_AR_BF16 4
+#endif
+    constexpr int AR0 = sizeof(DT) == 4 ? CAMAL_AR_F32 : CAMAL_AR_BF16;
+    constexpr int AR = AR0 < NCP ? AR0 : NCP;
     static_assert(NCP % AR == 0 && NCP % 2 == 0, "ring sizes must divide the chunk pairs per tap");
     const unsigned loff = (threadIdx.x & 63) * 16;
     const int h = (threadIdx.x & 63) >> 5;
@@ -477,11 +484,11 @@ __global__ __launch_bounds__((NWC + 1) * 64) void conv_kernel(const DT* __restri
 //     rectified accumulator, so no second accumulator is needed.
 //   HEAD (block 3): CAM head as in conv_kernel; the 128 x L feature map is never written.
 // ---------------------------------------------------------------------------------------
-// relu(acc + bias) of this wave's 32-channel x NT*32-column tile -> 128-channel LDS rows (row = column + guard)
-template <typename DT, int NT>
+// relu(acc + bias) of this wave's 32-channel x NT*32-column tile -> CH-channel LDS rows (row = column + guard)
+template <typename DT, int NT, int CH = 128>
 __device__ __forceinline__ void store_act_lds(char* dst, int row0, const f32x16 (&acc)[NT], const float (&bv)[4][4],
                                               int mt, int h) {
-    constexpr int RB = 128 * (int)sizeof(DT), CPR = RB / 16;
+    constexpr int RB = CH * (int)sizeof(DT), CPR = RB / 16;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int row = row0 + nt * 32;
@@ -497,9 +504,9 @@ __device__ __forceinline__ void store_act_lds(char* dst, int row0, const f32x16 
 }
 
 // rows just outside the window take the edge row's values (replicate padding of THIS layer's output)
-template <typename DT>
+template <typename DT, int CH = 128>
 __device__ __forceinline__ void fix_edges(char* buf, int guard, int g, int c_first, int c_last, bool lo, bool hi, int lane) {
-    constexpr int RB = 128 * (int)sizeof(DT), CPR = RB / 16;
+    constexpr int RB = CH * (int)sizeof(DT), CPR = RB / 16;
     if (lane < CPR) {
         if (lo) {
             const int src = c_first + guard;
@@ -786,6 +793,164 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
             }
         }
         __syncthreads();  // END
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Fused ResNetBlock 1 (camal_resnet.py:13-14,26-59 with in_channels = 1): the aggregate x goes in, the
+// 64-channel block output comes out; ConvBlock(k) on 1 channel runs on the VALU (stem_kernel's arithmetic,
+// same order), ConvBlock(7) and ConvBlock(3) on MFMA through LDS, and the skip BN(Conv1x1(x)) is a
+// per-element fma in the epilogue.  Per timestep this reads 4 bytes and writes one activation row, where
+// the per-layer path (stem, two conv launches) moves six activation rows through HBM and is bound by it.
+//
+// 8 waves, no loader wave (the tile's input is N + k - 1 floats): wave = channel half (32 of 64) x
+// quarter of the N computed columns.  Columns, halos and the per-layer replicate fix-ups are those of
+// block_kernel: positions p = t0 - 4 + c, T = N - 8 valid columns, A1 rows = column + 3, A2 rows =
+// column + 1.  The stem weights are wave-uniform: they come through scalar loads, one x value per lane
+// and tap from LDS.
+// ---------------------------------------------------------------------------------------
+struct Block1Args {
+    const float* x;    // [B][L]
+    void* out;         // [B][L][64]
+    const uint4 *w2, *w3;            // packed ConvBlock(7), ConvBlock(3) weights (64 -> 64)
+    const float *b2, *b3;
+    int L, ks1, tiles_per_window, total_tiles;
+};
+
+template <typename DT, int NT>
+struct Block1Geom {
+    static constexpr int ES = sizeof(DT);
+    static constexpr int NWC = 8, THREADS = NWC * 64;
+    static constexpr int N = (NWC / 2) * 32 * NT;   // computed columns per tile
+    static constexpr int T = N - 8;
+    static constexpr int RB = 64 * ES;              // activation row bytes
+    static constexpr int XS = N + 64;               // floats per x buffer (N + k - 1 <= N + 62)
+    static constexpr int A1_BYTES = (((N + 6) * RB) + 1023) & ~1023;
+    static constexpr int A2_BYTES = (((N + 2) * RB) + 1023) & ~1023;
+    static constexpr int LDS_BYTES = A1_BYTES + A2_BYTES + 2 * XS * 4;
+};
+
+template <typename DT, int NT>
+__global__ __launch_bounds__(512) void block1_kernel(Block1Args a, const float* __restrict__ stem_w /*[k][64]*/,
+                                                     const float* __restrict__ stem_b, const float* __restrict__ res_w,
+                                                     const float* __restrict__ res_b) {
+    using G = Block1Geom<DT, NT>;
+    constexpr int N = G::N, T = G::T, NCP = 64 / Elem<DT>::K_PER_PAIR;
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    char* A1 = lds;
+    char* A2 = lds + G::A1_BYTES;
+    float* xs = reinterpret_cast<float*>(lds + G::A1_BYTES + G::A2_BYTES);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int L = a.L, ks1 = a.ks1, pad1 = ks1 >> 1, tpw = a.tiles_per_window;
+    const int nx = N + ks1 - 1;  // x values per tile: positions t0 - 4 - pad1 + i, clamped (replicate padding of x)
+
+    auto load_x = [&](int tile, int i) {
+        const int b = tile / tpw, t0 = (tile - b * tpw) * T;
+        int p = t0 - 4 - pad1 + i;
+        p = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
+        return a.x[(size_t)b * L + p];
+    };
+    if ((int)threadIdx.x < nx && (int)blockIdx.x < a.total_tiles) xs[threadIdx.x] = load_x(blockIdx.x, threadIdx.x);
+    __syncthreads();
+
+    // stem role: channel half sh, 64 columns;  MFMA role: channel tile mt, NT column tiles
+    const int sh = wave & 1, scol = (wave >> 1) * 64 + lane;
+    const int mt = wave & 1, ng = wave >> 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int col0 = ng * NT * 32 + r;
+    const uint4* w2 = a.w2 + (size_t)mt * 7 * NCP * 64;
+    const uint4* w3 = a.w3 + (size_t)mt * 3 * NCP * 64;
+    const float* sw = stem_w + 32 * sh;
+
+    int it = 0;
+    for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x, ++it) {
+        const float* xc = xs + (it & 1) * G::XS;
+        float* xn = xs + ((it + 1) & 1) * G::XS;
+        const int b = tile / tpw, t0 = (tile - b * tpw) * T;
+        const bool lo = t0 == 0, hi = L - 1 - t0 + 4 < N;
+        const int c_first = 4 - t0, c_last = L - 1 - t0 + 4;
+        // next tile's x: issued now, parked in a register until the end of the tile
+        const int next = tile + gridDim.x;
+        float xpre = 0.f;
+        if (next < a.total_tiles && (int)threadIdx.x < nx) xpre = load_x(next, threadIdx.x);
+
+        // ---- ConvBlock(k), 1 -> 64, VALU: a1[c][co] = relu(b[co] + sum_j w[j][co] x[c + j])  -> A1 row c + 3
+        {
+            float sacc[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) sacc[i] = stem_b[32 * sh + i];
+            for (int j = 0; j < ks1; ++j) {
+                const float xv = xc[scol + j];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) sacc[i] = fmaf(sw[j * 64 + i], xv, sacc[i]);
+            }
+            constexpr int CPR = G::RB / 16;
+            const int row = scol + 3, s = swz<CPR>(row);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {  // 8 groups of 4 channels
+                const int boff = (32 * sh + 4 * q) * (int)sizeof(DT);
+                DT* p = reinterpret_cast<DT*>(A1 + row * G::RB + (((boff >> 4) ^ s) << 4) + (boff & 15));
+                store4(p, fmaxf(sacc[4 * q], 0.f), fmaxf(sacc[4 * q + 1], 0.f), fmaxf(sacc[4 * q + 2], 0.f),
+                       fmaxf(sacc[4 * q + 3], 0.f));
+            }
+        }
+        __syncthreads();
+        if (lo || hi) {
+            if (wave == 0) fix_edges<DT, 64>(A1, 3, 3, c_first, c_last, lo, hi, lane);
+            __syncthreads();
+        }
+        f32x16 acc[1][NT];
+        float bv[4][4];
+        auto zero_acc = [&]() {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[0][nt][i] = 0.f;
+        };
+        // ---- ConvBlock(7): A1 -> A2, rows = column + 1
+        zero_acc();
+        mma_layer<DT, 64, NT, 1>(A1, col0, 7, w2, acc);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) load4(a.b2 + 32 * mt + 8 * g + 4 * h, bv[g]);
+        store_act_lds<DT, NT, 64>(A2, col0 + 1, acc[0], bv, mt, h);
+        __syncthreads();
+        if (lo || hi) {
+            if (wave == 0) fix_edges<DT, 64>(A2, 1, 1, c_first, c_last, lo, hi, lane);
+            __syncthreads();
+        }
+        // ---- ConvBlock(3): A2 -> registers; out = relu(. + b3) + (wr x + br)   (skip added after the ReLU)
+        zero_acc();
+        mma_layer<DT, 64, NT, 1>(A2, col0, 3, w3, acc);
+        {
+            float wr[4][4], br[4][4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                load4(a.b3 + 32 * mt + 8 * g + 4 * h, bv[g]);
+                load4(res_w + 32 * mt + 8 * g + 4 * h, wr[g]);
+                load4(res_b + 32 * mt + 8 * g + 4 * h, br[g]);
+            }
+            DT* outp = reinterpret_cast<DT*>(a.out);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int c = col0 + nt * 32;
+                const int p = t0 - 4 + c;
+                if (c >= 4 && c < 4 + T && p < L) {
+                    const float xv = xc[c + pad1];
+                    const size_t o = ((size_t)b * L + p) * 64 + 32 * mt + 4 * h;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float v[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            v[i] = fmaxf(acc[0][nt][4 * g + i] + bv[g][i], 0.f) + fmaf(wr[g][i], xv, br[g][i]);
+                        store4(outp + o + 8 * g, v[0], v[1], v[2], v[3]);
+                    }
+                }
+            }
+        }
+        if (next < a.total_tiles && (int)threadIdx.x < nx) xn[threadIdx.x] = xpre;
+        __syncthreads();  // END: A1/A2 free, next x in place
     }
 }
 
