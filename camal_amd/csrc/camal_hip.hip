@@ -364,7 +364,7 @@ int launch_block(camal_ctx* c, hipStream_t s, const Layer& l1, const Layer& l2, 
 // fused block 1: x [BC][L] -> block output [BC][L][64]
 template <typename DT>
 int launch_block1(camal_ctx* c, hipStream_t s, const Member& m, const float* x, void* out, int BC, int L) {
-    constexpr int NTB = 2;
+    constexpr int NTB = sizeof(DT) == 2 ? 4 : 2;  // 512-column tiles in bf16, 256 in fp32 (LDS)
     using G = Block1Geom<DT, NTB>;
     auto kern = block1_kernel<DT, NTB>;
     static bool attr_set = false;

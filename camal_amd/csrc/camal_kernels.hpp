@@ -806,8 +806,9 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
 // 8 waves, no loader wave (the tile's input is N + k - 1 floats): wave = channel half (32 of 64) x
 // quarter of the N computed columns.  Columns, halos and the per-layer replicate fix-ups are those of
 // block_kernel: positions p = t0 - 4 + c, T = N - 8 valid columns, A1 rows = column + 3, A2 rows =
-// column + 1.  The stem weights are wave-uniform: they come through scalar loads, one x value per lane
-// and tap from LDS.
+// column + 1.  The stem weights are wave-uniform: they come through scalar loads, one x value per lane,
+// column and tap from LDS.  bf16 runs 512-column tiles (NT = 4: four MFMAs per streamed weight fragment,
+// as in block_kernel), fp32 256-column tiles (LDS).
 // ---------------------------------------------------------------------------------------
 struct Block1Args {
     const float* x;    // [B][L]
@@ -851,11 +852,16 @@ __global__ __launch_bounds__(512) void block1_kernel(Block1Args a, const float* 
         p = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
         return a.x[(size_t)b * L + p];
     };
-    if ((int)threadIdx.x < nx && (int)blockIdx.x < a.total_tiles) xs[threadIdx.x] = load_x(blockIdx.x, threadIdx.x);
+    constexpr int XPT = (G::XS + 511) / 512;  // x values per thread
+    if ((int)blockIdx.x < a.total_tiles)
+#pragma unroll
+        for (int u = 0; u < XPT; ++u)
+            if ((int)threadIdx.x + 512 * u < nx) xs[threadIdx.x + 512 * u] = load_x(blockIdx.x, threadIdx.x + 512 * u);
     __syncthreads();
 
     // stem role: channel half sh, 64 columns;  MFMA role: channel tile mt, NT column tiles
-    const int sh = wave & 1, scol = (wave >> 1) * 64 + lane;
+    constexpr int SC = NT / 2;  // stem columns per lane (a wave covers N/4 = 64 SC columns)
+    const int sh = wave & 1, scol = (wave >> 1) * 64 * SC + lane;
     const int mt = wave & 1, ng = wave >> 1;
     const int r = lane & 31, h = lane >> 5;
     const int col0 = ng * NT * 32 + r;
@@ -872,27 +878,42 @@ __global__ __launch_bounds__(512) void block1_kernel(Block1Args a, const float* 
         const int c_first = 4 - t0, c_last = L - 1 - t0 + 4;
         // next tile's x: issued now, parked in a register until the end of the tile
         const int next = tile + gridDim.x;
-        float xpre = 0.f;
-        if (next < a.total_tiles && (int)threadIdx.x < nx) xpre = load_x(next, threadIdx.x);
+        float xpre[XPT];
+#pragma unroll
+        for (int u = 0; u < XPT; ++u) {
+            xpre[u] = 0.f;
+            if (next < a.total_tiles && (int)threadIdx.x + 512 * u < nx) xpre[u] = load_x(next, threadIdx.x + 512 * u);
+        }
 
         // ---- ConvBlock(k), 1 -> 64, VALU: a1[c][co] = relu(b[co] + sum_j w[j][co] x[c + j])  -> A1 row c + 3
         {
-            float sacc[32];
+            float sacc[SC][32];
 #pragma unroll
-            for (int i = 0; i < 32; ++i) sacc[i] = stem_b[32 * sh + i];
+            for (int u = 0; u < SC; ++u)
+#pragma unroll
+                for (int i = 0; i < 32; ++i) sacc[u][i] = stem_b[32 * sh + i];
             for (int j = 0; j < ks1; ++j) {
-                const float xv = xc[scol + j];
+                float xv[SC];
 #pragma unroll
-                for (int i = 0; i < 32; ++i) sacc[i] = fmaf(sw[j * 64 + i], xv, sacc[i]);
+                for (int u = 0; u < SC; ++u) xv[u] = xc[scol + 64 * u + j];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const float wv = sw[j * 64 + i];
+#pragma unroll
+                    for (int u = 0; u < SC; ++u) sacc[u][i] = fmaf(wv, xv[u], sacc[u][i]);
+                }
             }
             constexpr int CPR = G::RB / 16;
-            const int row = scol + 3, s = swz<CPR>(row);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {  // 8 groups of 4 channels
-                const int boff = (32 * sh + 4 * q) * (int)sizeof(DT);
-                DT* p = reinterpret_cast<DT*>(A1 + row * G::RB + (((boff >> 4) ^ s) << 4) + (boff & 15));
-                store4(p, fmaxf(sacc[4 * q], 0.f), fmaxf(sacc[4 * q + 1], 0.f), fmaxf(sacc[4 * q + 2], 0.f),
-                       fmaxf(sacc[4 * q + 3], 0.f));
+            for (int u = 0; u < SC; ++u) {
+                const int row = scol + 64 * u + 3, s = swz<CPR>(row);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {  // 8 groups of 4 channels
+                    const int boff = (32 * sh + 4 * q) * (int)sizeof(DT);
+                    DT* p = reinterpret_cast<DT*>(A1 + row * G::RB + (((boff >> 4) ^ s) << 4) + (boff & 15));
+                    store4(p, fmaxf(sacc[u][4 * q], 0.f), fmaxf(sacc[u][4 * q + 1], 0.f), fmaxf(sacc[u][4 * q + 2], 0.f),
+                           fmaxf(sacc[u][4 * q + 3], 0.f));
+                }
             }
         }
         __syncthreads();
@@ -949,7 +970,9 @@ __global__ __launch_bounds__(512) void block1_kernel(Block1Args a, const float* 
                 }
             }
         }
-        if (next < a.total_tiles && (int)threadIdx.x < nx) xn[threadIdx.x] = xpre;
+#pragma unroll
+        for (int u = 0; u < XPT; ++u)
+            if (next < a.total_tiles && (int)threadIdx.x + 512 * u < nx) xn[threadIdx.x + 512 * u] = xpre[u];
         __syncthreads();  // END: A1/A2 free, next x in place
     }
 }
