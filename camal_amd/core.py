@@ -173,24 +173,32 @@ class CamAL(object):
             raise ValueError("Provided test data need to be given in NILM standard (4D numpy array)")
 
         data = data_test[:, 0, 0, :]
-        if appliance_mean_on_power is not None:
+        want_power = appliance_mean_on_power is not None
+        if want_power:
             if scaler is None:
                 warnings.warn("No scaler provided for inverse_transform, are you sure you didn't scale the data for training?")
             mul, add = _scaler_affine(scaler)
-            soft_label, prob_detect, y_hat = self._predict_impl(
-                data, return_prob=True, p_on=float(appliance_mean_on_power), scale_mul=mul, scale_add=add)
+            res = self._localize_device(data, p_on=float(appliance_mean_on_power), scale_mul=mul, scale_add=add)
         else:
-            soft_label, prob_detect = self._predict_impl(data, return_prob=True)
+            res = self._localize_device(data)
+        prob_detect = res["prob"].cpu().numpy().reshape(-1, 1)
 
+        # localization metrics: states and powers stay on the device, only twelve sums come back
         y_state = data_test[:, 1, 1, :].ravel().astype(dtype=int)
-        y_hat_state = soft_label.ravel().astype(dtype=int)
-
-        if appliance_mean_on_power is not None:
+        y = None
+        if want_power:
             rescaled = scaler.inverse_transform(data_test) if scaler is not None else data_test
             y = rescaled[:, 1, 0, :].ravel()
-            metric_softlabel = self.loc_metrics(y, y_hat.ravel(), y_state, y_hat_state)
-        else:
-            metric_softlabel = self.loc_metrics(y=None, y_hat=None, y_state=y_state, y_hat_state=y_hat_state)
+        if isinstance(self.loc_metrics, NILMmetrics):
+            from .metrics import nilm_sums_device
+            sums, n = nilm_sums_device(y=y, y_hat=res["power"] if want_power else None, y_state=y_state,
+                                       y_hat_state=res["state"])
+            metric_softlabel = self.loc_metrics.from_sums(sums, n, regression=want_power)
+        else:  # a caller-supplied metric object gets host arrays, like the reference's
+            y_hat_state = res["state"].cpu().numpy().ravel().astype(dtype=int)
+            y_hat = res["power"].cpu().numpy().astype(np.float64).ravel() if want_power else None
+            metric_softlabel = self.loc_metrics(y, y_hat, y_state, y_hat_state) if want_power else \
+                self.loc_metrics(y=None, y_hat=None, y_state=y_state, y_hat_state=y_hat_state)
 
         _, y_clf_true = nilmdataset_to_clfdataset(data_test)
         metric_classif = self.clf_metrics(y=y_clf_true.ravel(), y_hat=prob_detect.ravel())
@@ -223,12 +231,7 @@ class CamAL(object):
         if self.list_resnet_predictors is None:
             self.eval()
 
-        is64 = data.dtype != np.float32
-        res = self._ensemble.localize(
-            np.ascontiguousarray(data, dtype=np.float32),
-            x64=np.ascontiguousarray(data, dtype=np.float64) if is64 else None,
-            y=y, w_ma=w_ma, gate_mode=int(bool(self.prefilter)), pred_f64=is64,
-            p_on=p_on, scale_mul=scale_mul, scale_add=scale_add)
+        res = self._localize_device(data, y=y, w_ma=w_ma, p_on=p_on, scale_mul=scale_mul, scale_add=scale_add)
         prediction = res["state"].cpu().numpy().astype(np.float64)
         prob_detect = res["prob"].cpu().numpy().reshape(-1, 1)
         out = [prediction]
@@ -237,6 +240,25 @@ class CamAL(object):
         if p_on is not None:
             out.append(res["power"].cpu().numpy().astype(np.float64))
         return out[0] if len(out) == 1 else tuple(out)
+
+    def _localize_device(self, data, y=None, w_ma=5, p_on=None, scale_mul=1.0, scale_add=0.0):
+        """predict's checks + the fused HIP path; results stay on the device (dict of torch tensors)."""
+        if not self.is_fitted:
+            raise ValueError(
+                "CamAL instance is not fitted. Train CamAL or load a fitted instance of CamAL before trying to predict.")
+        data = np.asarray(data)
+        assert len(data.shape) <= 2, (
+            f"Input data need to be a 1D or 2D (batched) numpy array, got a {len(data.shape)}D array of size {data.shape}.")
+        if len(data.shape) == 1:
+            data = np.expand_dims(data, axis=0)
+        if self.list_resnet_predictors is None:
+            self.eval()
+        is64 = data.dtype != np.float32
+        return self._ensemble.localize(
+            np.ascontiguousarray(data, dtype=np.float32),
+            x64=np.ascontiguousarray(data, dtype=np.float64) if is64 else None,
+            y=y, w_ma=w_ma, gate_mode=int(bool(self.prefilter)), pred_f64=is64,
+            p_on=p_on, scale_mul=scale_mul, scale_add=scale_add)
 
     def __call__(self, data: np.array, y: np.array = None, return_prob: bool = False):
         return self.predict(data, y=y, return_prob=return_prob)

@@ -663,6 +663,32 @@ int camal_attention(const double* soft, const double* x, int B, int L, int w_ma,
     return 0;
 }
 
+static int nilm_blocks(size_t n) {
+    const size_t want = (n + (size_t)NILM_THREADS * 8 - 1) / ((size_t)NILM_THREADS * 8);
+    return (int)std::max<size_t>(1, std::min<size_t>(want, NILM_MAX_BLOCKS));
+}
+
+size_t camal_nilm_workspace_bytes(size_t n) { return (size_t)nilm_blocks(n) * NILM_NSUMS * sizeof(double); }
+
+int camal_nilm_sums(const float* y32, const double* y64, const float* yhat, const int8_t* ystate, const float* yhat_state,
+                    size_t n, double* sums_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!sums_out || !workspace) return fail(CAMAL_ERR_ARG, "sums_out and workspace_dev are required");
+    if (n < 1) return fail(CAMAL_ERR_ARG, "n must be >= 1");
+    if (y32 && y64) return fail(CAMAL_ERR_ARG, "pass the true power as float32 OR float64, not both");
+    if ((y32 || y64) && !yhat) return fail(CAMAL_ERR_ARG, "y given without y_hat");
+    if ((ystate != nullptr) != (yhat_state != nullptr)) return fail(CAMAL_ERR_ARG, "y_state and y_hat_state come together");
+    if (workspace_bytes < camal_nilm_workspace_bytes(n)) return fail(CAMAL_ERR_ARG, "workspace smaller than camal_nilm_workspace_bytes(n)");
+    NilmArgs a;
+    a.y32 = y32; a.y64 = y64; a.yhat = yhat; a.ystate = ystate; a.yhat_state = yhat_state; a.n = n;
+    a.partial = (double*)workspace;
+    const int nb = nilm_blocks(n);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(nilm_partial_kernel, dim3(nb), dim3(NILM_THREADS), 0, s, a);
+    hipLaunchKernelGGL(nilm_final_kernel, dim3(1), dim3(NILM_NSUMS * 64), 0, s, a.partial, nb, sums_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int camal_set_profiling(camal_ctx* c, int enabled) {
     if (!c) return fail(CAMAL_ERR_ARG, "null context");
     c->prof = enabled != 0;

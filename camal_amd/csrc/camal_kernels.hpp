@@ -1254,4 +1254,87 @@ __global__ __launch_bounds__(256) void attention_kernel(const double* __restrict
     out[(size_t)b * L + t] = attention_state(sum, w, 1.0 / (double)w, x[(size_t)b * L + t]);
 }
 
+// ---------------------------------------------------------------------------------------
+// Sums behind NILMmetrics (src/helpers/other.py:112-159) and CamAL.test (core.py:201-231) in one pass
+// over the flattened [N*L] arrays, so that states and powers never leave the device:
+//   y, y_hat -> nan_to_num (nan, +-inf -> 0), float64:  sum|yh-y|, sum(yh-y)^2, sum|y|, sum y^2, sum y,
+//   sum yh, sum min(yh,y), sum max(yh,y);  y_state, int(y_hat_state) -> TP, TN, FP, FN (labels other than
+//   0/1 fall in none of the four, as in camal_amd/metrics.py).
+// HBM-bound: 13 (f32 y) or 17 (f64 y) bytes per element.  Two stages, fixed order: deterministic.
+// ---------------------------------------------------------------------------------------
+#define NILM_NSUMS 12
+#define NILM_THREADS 256
+#define NILM_MAX_BLOCKS 2048
+
+struct NilmArgs {
+    const float* y32;        // true appliance power (either y32 or y64; both null: no regression sums)
+    const double* y64;
+    const float* yhat;       // estimated power (float32, post_kernel's power_out)
+    const int8_t* ystate;    // true on/off labels (0/1), or null
+    const float* yhat_state; // estimated states (post_kernel's state_out: -1, -0, 0, 1)
+    size_t n;
+    double* partial;         // [gridDim.x][NILM_NSUMS]
+};
+
+__device__ __forceinline__ double nan_to_num0(double v) { return (v - v == 0.0) ? v : 0.0; }  // finite ? v : 0
+
+__global__ __launch_bounds__(NILM_THREADS) void nilm_partial_kernel(NilmArgs a) {
+    __shared__ double sh[NILM_THREADS / 64][NILM_NSUMS];
+    double acc[NILM_NSUMS];
+#pragma unroll
+    for (int k = 0; k < NILM_NSUMS; ++k) acc[k] = 0.0;
+    const bool reg = (a.y32 != nullptr || a.y64 != nullptr) && a.yhat != nullptr;
+    const bool cls = a.ystate != nullptr && a.yhat_state != nullptr;
+    for (size_t i = (size_t)blockIdx.x * NILM_THREADS + threadIdx.x; i < a.n; i += (size_t)gridDim.x * NILM_THREADS) {
+        if (reg) {
+            const double y = nan_to_num0(a.y64 ? a.y64[i] : (double)a.y32[i]);
+            const double yh = nan_to_num0((double)a.yhat[i]);
+            const double d = yh - y;
+            acc[0] += fabs(d);
+            acc[1] += d * d;
+            acc[2] += fabs(y);
+            acc[3] += y * y;
+            acc[4] += y;
+            acc[5] += yh;
+            acc[6] += fmin(yh, y);
+            acc[7] += fmax(yh, y);
+        }
+        if (cls) {
+            const int ys = a.ystate[i];
+            const float hs = a.yhat_state[i];
+            const int yh = (hs - hs == 0.f) ? (int)hs : 0;  // astype(int) of -1, -0, 0, 1 (nan_to_num first)
+            acc[8] += (double)(ys == 1 && yh == 1);
+            acc[9] += (double)(ys == 0 && yh == 0);
+            acc[10] += (double)(ys == 0 && yh == 1);
+            acc[11] += (double)(ys == 1 && yh == 0);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NILM_NSUMS; ++k) {
+        double v = acc[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) sh[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NILM_NSUMS) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < NILM_THREADS / 64; ++w) v += sh[w][threadIdx.x];
+        a.partial[(size_t)blockIdx.x * NILM_NSUMS + threadIdx.x] = v;
+    }
+}
+
+// sums[k] = sum over blocks of partial[b][k]: 64 lanes per sum over a strided subset, then a shuffle tree
+__global__ __launch_bounds__(NILM_NSUMS * 64) void nilm_final_kernel(const double* __restrict__ partial, int nblocks,
+                                                                     double* __restrict__ sums) {
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double v = 0.0;
+    for (int b = lane; b < nblocks; b += 64) v += partial[(size_t)b * NILM_NSUMS + k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) sums[k] = v;
+}
+
 }  // namespace camal

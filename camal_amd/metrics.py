@@ -1,7 +1,9 @@
-"""Host-side metrics with the reference's key names (``src/helpers/other.py:86-159``).
+"""Metrics with the reference's key names (``src/helpers/other.py:86-159``).
 
-Out of the hot path: NumPy restatements of the sklearn calls the reference
-wraps, for binary labels.  ``CamAL.test`` hands them host arrays.
+NumPy restatements of the sklearn calls the reference wraps, for binary labels, for host arrays; and
+the device route ``CamAL.test`` takes for the localization metrics: the sums behind
+``NILMmetrics`` come from ``camal_nilm_sums`` (one HBM pass over states and powers that stay on the
+device), the formulas on top of the twelve sums are shared with the host route.
 """
 from __future__ import annotations
 
@@ -23,7 +25,10 @@ def _div(a, b):
 
 
 def _binary_scores(y, yh):
-    tp, tn, fp, fn = _confusion(y, yh)
+    return _scores_from_counts(*_confusion(y, yh))
+
+
+def _scores_from_counts(tp, tn, fp, fn):
     n = tp + tn + fp + fn
     prec, rec = _div(tp, tp + fp), _div(tp, tp + fn)
     spec = _div(tn, tn + fp)
@@ -82,11 +87,72 @@ class Classifmetrics:
         return out
 
 
+def nilm_sums_device(y=None, y_hat=None, y_state=None, y_hat_state=None):
+    """The twelve sums of ``camal_nilm_sums`` (include/camal_hip.h) for device or host inputs.
+    ``y_hat`` / ``y_hat_state``: float32 tensors as ``Ensemble.localize`` returns them (``power``, ``state``);
+    ``y``: true power, float32 or float64; ``y_state``: true labels (converted to int8).  -> (sums[12], n)"""
+    import ctypes as C
+
+    import torch
+
+    from . import _lib
+    lib = _lib.load()
+    ref = y_hat if y_hat is not None else y_hat_state
+    dev = ref.device if torch.is_tensor(ref) and ref.is_cuda else torch.device("cuda", torch.cuda.current_device())
+
+    def put(a, dtype):
+        if a is None:
+            return None
+        t = a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
+        return t.to(device=dev, dtype=dtype).contiguous().reshape(-1)
+
+    y32 = y64 = None
+    if y is not None:
+        is32 = (y.dtype == torch.float32) if torch.is_tensor(y) else (np.asarray(y).dtype == np.float32)
+        if is32:
+            y32 = put(y, torch.float32)
+        else:
+            y64 = put(y, torch.float64)
+    yh = put(y_hat, torch.float32)
+    ys = put(np.asarray(y_state).astype(np.int64) if y_state is not None and not torch.is_tensor(y_state) else y_state,
+             torch.int8)
+    yhs = put(y_hat_state, torch.float32)
+    n = int((yh if yh is not None else yhs).numel())
+    with torch.cuda.device(dev):
+        ws = torch.empty(int(lib.camal_nilm_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+        sums = torch.empty(12, dtype=torch.float64, device=dev)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.camal_nilm_sums(_lib.ptr(y32), _lib.ptr(y64), _lib.ptr(yh), _lib.ptr(ys), _lib.ptr(yhs), n,
+                                       _lib.ptr(sums), _lib.ptr(ws), ws.numel(), stream))
+    return sums.cpu().numpy(), n
+
+
 class NILMmetrics:
     """other.py:112-159."""
 
     def __init__(self, round_to=3):
         self.round_to = round_to
+
+    def from_sums(self, sums, n, regression=True, classification=True):
+        """Same keys and rounding from the twelve sums of ``camal_nilm_sums``."""
+        r = self.round_to
+        s = [float(v) for v in sums]
+        metrics = {}
+        if regression:
+            mse = s[1] / n
+            metrics["MAE"] = round(s[0] / n, r)
+            metrics["MSE"] = round(mse, r)
+            metrics["RMSE"] = round(float(np.sqrt(mse)), r)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                metrics["TECA"] = round(float(1 - np.float64(s[0]) / (2 * np.float64(s[2]))), r)
+                metrics["NDE"] = round(float(np.float64(s[1]) / np.float64(s[3])), r)
+                metrics["SAE"] = round(float(np.abs(np.float64(s[5]) - np.float64(s[4])) / np.float64(s[4])), r)
+                metrics["MR"] = round(float(np.float64(s[6]) / np.float64(s[7])), r)
+        if classification:
+            m = _scores_from_counts(int(round(s[8])), int(round(s[9])), int(round(s[10])), int(round(s[11])))
+            for k in ("ACCURACY", "BALANCED_ACCURACY", "PRECISION", "RECALL", "F1_SCORE"):
+                metrics[k] = round(m[k], r)
+        return metrics
 
     def __call__(self, y=None, y_hat=None, y_state=None, y_hat_state=None):
         r = self.round_to

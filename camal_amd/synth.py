@@ -49,3 +49,27 @@ def ideal_windows(n=128, length=510, seed=0, dtype=np.float32, return_labels=Tru
     """BASELINE config 4: IDEAL-shaped training windows (no cutoff), ~50/50 labels."""
     x, y = _windows(n, length, seed, _IDEAL_PULSES, 1e9, 0.7, dtype)
     return (x, y) if return_labels else x
+
+
+def metric_arrays(seed, n=4000):
+    """Flat arrays shaped like what ``CamAL.test`` hands the metrics (core.py:199-231): true / estimated power in W
+    (the estimate holds a few NaN / +-inf entries, which the metrics zero), true states 0/1, estimated states as
+    the attention module emits them for unsigned inputs (-0, 0, 1; the reference's sklearn calls refuse -1), window labels and detection scores with ties.
+    -> (y, y_hat, y_state, y_hat_state, y_clf, score)"""
+    rng = np.random.default_rng(seed)
+    y_state = (rng.random(n) < 0.3).astype(np.int64)
+    y = y_state * rng.uniform(500.0, 2500.0, n)
+    flip = rng.random(n) < 0.15
+    hat_on = np.where(flip, 1 - y_state, y_state)
+    y_hat_state = hat_on.astype(np.float32)
+    neg = rng.random(n) < 0.02
+    y_hat_state[neg & (hat_on == 0)] = -0.0
+    y_hat = np.minimum(np.maximum(y_hat_state, 0) * 2000.0, rng.uniform(100.0, 6000.0, n)).astype(np.float32)
+    bad = rng.choice(n, 6, replace=False)
+    y_hat[bad[:2]] = np.nan
+    y_hat[bad[2:4]] = np.inf
+    y_hat[bad[4:]] = -np.inf
+    m = n // 16
+    y_clf = (rng.random(m) < 0.4).astype(np.int64)
+    score = np.round(np.clip(0.5 + 0.35 * (2 * y_clf - 1) * rng.random(m) + 0.2 * rng.normal(size=m), 0, 1), 2)
+    return y, y_hat, y_state, y_hat_state, y_clf, score

@@ -123,6 +123,24 @@ int camal_postprocess(int n_members, const float* cam_dev, const float* logits_d
 int camal_attention(const double* soft_dev, const double* x_dev, int B, int L, int w_ma,
                     double* state_out, void* stream);
 
+/* Reductions behind NILMmetrics (src/helpers/other.py:112-159) as CamAL.test applies them to the
+ * flattened states and powers (core.py:199-231), so that [N][L] results never round-trip to the host.
+ * All arrays are DEVICE pointers of n elements:
+ *   y32_dev / y64_dev  true appliance power as float32 or float64 (one of them, or both NULL to skip
+ *                      the regression sums); yhat_dev estimated power (camal_localize power_out);
+ *   ystate_dev         true on/off labels as int8 (0/1); yhat_state_dev estimated states
+ *                      (camal_localize state_out); both NULL to skip the confusion counts.
+ *   sums_out           12 doubles: sum|yh-y|, sum(yh-y)^2, sum|y|, sum y^2, sum y, sum yh, sum min(yh,y),
+ *                      sum max(yh,y) (after nan_to_num of y, yh: nan/inf -> 0), TP, TN, FP, FN.
+ *   workspace_dev      scratch of camal_nilm_workspace_bytes(n) bytes (per-block partials; the library
+ *                      allocates nothing).  Deterministic: fixed two-stage summation order.
+ * MAE = s0/n, MSE = s1/n, TECA = 1 - s0/(2 s2), NDE = s1/s3, SAE = |s5-s4|/s4, MR = s6/s7.           */
+#define CAMAL_NILM_NSUMS 12
+size_t camal_nilm_workspace_bytes(size_t n);
+int camal_nilm_sums(const float* y32_dev, const double* y64_dev, const float* yhat_dev, const int8_t* ystate_dev,
+                    const float* yhat_state_dev, size_t n, double* sums_out, void* workspace_dev,
+                    size_t workspace_bytes, void* stream);
+
 /* ------------------------------- training (one ResNet member) -------------------------------
  * Replaces the per-batch body of BasedClassifTrainer.__train (torch_trainer.py:281-298) for
  * CamALResNet in train() mode: forward with BatchNorm batch statistics (biased variance,

@@ -196,7 +196,33 @@ def train_case(name, k, seed, n, length, batch, epochs, lr=1e-3):
           f"acc={np.round(tr.accuracy_train_history, 3).tolist()} size={os.path.getsize(os.path.join(HERE, name + '.npz')) / 1024:.0f} KB")
 
 
+def metrics_case(name="metrics_ref"):
+    """NILMmetrics / Classifmetrics of the reference (other.py:86-159, sklearn underneath) on seeded arrays:
+    powers with NaN / +-inf entries, states as post_kernel emits them for unsigned inputs (-0, 0, 1), detection scores
+    with ties.  Inputs come from seeds, only the reference's numbers are stored."""
+    from src.helpers.other import Classifmetrics, NILMmetrics
+    loc_keys = ["MAE", "MSE", "RMSE", "TECA", "NDE", "SAE", "MR", "ACCURACY", "BALANCED_ACCURACY", "PRECISION",
+                "RECALL", "F1_SCORE"]
+    clf_keys = ["ACCURACY", "BALANCED_ACCURACY", "PRECISION", "RECALL", "F1_SCORE", "F1_SCORE_MACRO",
+                "ROC_AUC_SCORE", "AP"]
+    seeds = [301, 302, 303, 304]
+    loc = np.zeros((len(seeds), len(loc_keys)))
+    clf = np.zeros((len(seeds), len(clf_keys)))
+    for i, seed in enumerate(seeds):
+        y, y_hat, y_state, y_hat_state, y_clf, score = synth.metric_arrays(seed)
+        m = NILMmetrics()(y=y, y_hat=y_hat, y_state=y_state, y_hat_state=y_hat_state)
+        loc[i] = [float(m[k]) for k in loc_keys]
+        c = Classifmetrics()(y_clf, score)
+        clf[i] = [float(c[k]) for k in clf_keys]
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), seeds=np.array(seeds), loc_keys=np.array(loc_keys),
+                        clf_keys=np.array(clf_keys), loc=loc, clf=clf)
+    print(f"{name}: loc[0]={loc[0].tolist()} clf[0]={clf[0].tolist()}")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "metrics":
+        return metrics_case()
+    metrics_case()
     train_case("train_k7_l96", k=7, seed=201, n=48, length=96, batch=16, epochs=2)
     train_case("train_k25_l70", k=25, seed=202, n=24, length=70, batch=12, epochs=1)
     # 1. the BASELINE config-1 shape, shrunk: full ensemble, float32 data

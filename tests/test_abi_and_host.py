@@ -52,6 +52,8 @@ def test_argument_errors_without_gpu():
     ks = (ctypes.c_int * 1)(7)
     assert lib.camal_create(0, 1, ks, 7, ctypes.byref(h)) == -1  # bad precision
     assert lib.camal_create(0, 0, ks, 0, ctypes.byref(h)) == -1  # no members
+    assert lib.camal_nilm_sums(None, None, None, None, None, 10, None, None, 0, None) == -1
+    assert lib.camal_nilm_workspace_bytes(1) == 12 * 8 and lib.camal_nilm_workspace_bytes(1 << 40) == 2048 * 12 * 8
     assert lib.camal_postprocess(1, None, None, None, None, None, 1, 1, 5, 0, 0, 0.0, 1.0, 0.0, None, None, None, None, None) == -1
 
 
@@ -132,6 +134,20 @@ def test_metrics_keys_and_values():
     n = NILMmetrics()(y=np.array([0.0, 10.0, 20.0]), y_hat=np.array([0.0, 10.0, 10.0]),
                       y_state=np.array([0, 1, 1]), y_hat_state=np.array([0, 1, 1]))
     assert n["MAE"] == round(10 / 3, 3) and n["F1_SCORE"] == 1.0 and n["TECA"] == round(1 - 10 / 60, 3)
+
+
+def test_metrics_match_the_reference_fixture():
+    """tests/golden/metrics_ref.npz holds the reference's own NILMmetrics / Classifmetrics numbers (sklearn)."""
+    from camal_amd import synth
+    from camal_amd.metrics import Classifmetrics, NILMmetrics
+    from tests.helpers import load_case
+    c = load_case("metrics_ref")
+    for i, seed in enumerate(c["seeds"]):
+        y, y_hat, y_state, y_hat_state, y_clf, score = synth.metric_arrays(int(seed))
+        m = NILMmetrics()(y=y, y_hat=y_hat, y_state=y_state, y_hat_state=y_hat_state)
+        assert [m[k] for k in c["loc_keys"]] == c["loc"][i].tolist()
+        q = Classifmetrics()(y_clf, score)
+        assert [q[k] for k in c["clf_keys"]] == c["clf"][i].tolist()
 
 
 def test_nilm_to_clf_labels():

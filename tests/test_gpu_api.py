@@ -115,6 +115,34 @@ def test_camal_load_and_test(tmp_path):
     assert "MAE" not in loc2 and "F1_SCORE" in loc2
 
 
+def test_device_metric_sums_match_the_reference_fixture():
+    """camal_nilm_sums (one pass over device arrays) -> NILMmetrics.from_sums == the reference's NILMmetrics."""
+    import torch
+    from camal_amd import synth
+    from camal_amd.metrics import NILMmetrics, nilm_sums_device
+    c = load_case("metrics_ref")
+    for i, seed in enumerate(c["seeds"]):
+        y, y_hat, y_state, y_hat_state, _, _ = synth.metric_arrays(int(seed))
+        for yy in (y, y.astype(np.float32)):
+            sums, n = nilm_sums_device(y=yy, y_hat=torch.from_numpy(y_hat).cuda(), y_state=y_state,
+                                       y_hat_state=torch.from_numpy(y_hat_state).cuda())
+            assert n == len(y)
+            ok = np.isfinite(y_hat)
+            d = np.where(ok, y_hat, 0).astype(np.float64) - yy.astype(np.float64)
+            assert abs(sums[0] - np.abs(d).sum()) <= 1e-12 * np.abs(d).sum()
+            assert sums[8:].tolist() == [float(((y_state == a) & (np.abs(y_hat_state) == b)).sum())
+                                         for a, b in ((1, 1), (0, 0), (0, 1), (1, 0))]
+        m = NILMmetrics().from_sums(*nilm_sums_device(y=y, y_hat=torch.from_numpy(y_hat).cuda(), y_state=y_state,
+                                                      y_hat_state=torch.from_numpy(y_hat_state).cuda()))
+        assert [m[k] for k in c["loc_keys"]] == c["loc"][i].tolist()
+    # states only (CamAL.test without a mean on-power), and a size that is not a multiple of anything
+    y, y_hat, y_state, y_hat_state, _, _ = synth.metric_arrays(7, n=100003)
+    sums, n = nilm_sums_device(y_state=y_state, y_hat_state=torch.from_numpy(y_hat_state).cuda())
+    assert n == 100003 and sums[:8].tolist() == [0.0] * 8 and sums[8:].sum() == n
+    m = NILMmetrics().from_sums(sums, n, regression=False)
+    assert m == NILMmetrics()(y_state=y_state, y_hat_state=y_hat_state)
+
+
 def test_attention_module_and_subsequence_class():
     from oracle import camal_oracle as oracle
     c = load_case("ensemble_l256")
