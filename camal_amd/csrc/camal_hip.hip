@@ -127,29 +127,37 @@ inline uint16_t f2bf(float f) {  // round to nearest even, NaN stays NaN
     return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1)) >> 16);
 }
 
-// w [cout][cin][ks] fp32 -> A-fragment order [mt][tap][chunk pair][lane][16 B]
-// fp32: lane (i = l&31, h = l>>5), element s  <-> W[32 mt + i][8 cp + 4 h + s][tap]
-// bf16: lane (i, h), element jj               <-> W[32 mt + i][16 cp + 8 h + jj][tap]
+// w [cout][cin][ks] fp32 -> A-fragment order, one coalesced 1 KiB block per fragment:
+// fp32 (32x32x2):   [mt][tap][chunk pair cp][lane][16 B]; lane (i = l&31, h = l>>5), element s
+//                   <-> W[32 mt + i][8 cp + 4 h + s][tap]
+// bf16 (16x16x32):  [mt][tap][group gk of 32 channels][mi][lane][16 B]; lane (i = l&15, q = l>>4), element jj
+//                   <-> W[32 mt + 16 mi + i][32 gk + 8 kblock(q) + jj][tap]   (kblock: Frag<__bf16>, LDS banking)
 std::vector<char> pack_weights(const float* w, int cout, int cin, int ks, int precision) {
-    const int kpp = precision == CAMAL_FP32 ? 8 : 16;
-    const int ncp = cin / kpp, mtn = cout / 32;
-    std::vector<char> out((size_t)mtn * ks * ncp * 1024);
+    const int mtn = cout / 32;
+    std::vector<char> out((size_t)mtn * ks * (cin / 8) * (precision == CAMAL_FP32 ? 1024 : 512));
+    char* dst = out.data();
     for (int mt = 0; mt < mtn; ++mt)
-        for (int j = 0; j < ks; ++j)
-            for (int cp = 0; cp < ncp; ++cp)
-                for (int l = 0; l < 64; ++l) {
-                    char* dst = out.data() + ((((size_t)mt * ks + j) * ncp + cp) * 64 + l) * 16;
-                    const int co = 32 * mt + (l & 31), h = l >> 5;
-                    if (precision == CAMAL_FP32) {
+        for (int j = 0; j < ks; ++j) {
+            if (precision == CAMAL_FP32) {
+                for (int cp = 0; cp < cin / 8; ++cp)
+                    for (int l = 0; l < 64; ++l, dst += 16) {
+                        const int co = 32 * mt + (l & 31), h = l >> 5;
                         float v[4];
                         for (int s = 0; s < 4; ++s) v[s] = w[((size_t)co * cin + 8 * cp + 4 * h + s) * ks + j];
                         memcpy(dst, v, 16);
-                    } else {
-                        uint16_t v[8];
-                        for (int jj = 0; jj < 8; ++jj) v[jj] = f2bf(w[((size_t)co * cin + 16 * cp + 8 * h + jj) * ks + j]);
-                        memcpy(dst, v, 16);
                     }
-                }
+            } else {
+                for (int gk = 0; gk < cin / 32; ++gk)
+                    for (int mi = 0; mi < 2; ++mi)
+                        for (int l = 0; l < 64; ++l, dst += 16) {
+                            const int co = 32 * mt + 16 * mi + (l & 15), q = l >> 4;
+                            const int kb = ((q & 1) << 1) | (q >> 1);  // Frag<__bf16>::kblock
+                            uint16_t v[8];
+                            for (int jj = 0; jj < 8; ++jj) v[jj] = f2bf(w[((size_t)co * cin + 32 * gk + 8 * kb + jj) * ks + j]);
+                            memcpy(dst, v, 16);
+                        }
+            }
+        }
     return out;
 }
 
@@ -173,8 +181,7 @@ template <typename DT> struct BlockNT;
 template <> struct BlockNT<float> { static constexpr int NT = 2; };
 template <> struct BlockNT<__bf16> { static constexpr int NT = 4; };
 
-// out-channel tiles per wave: NWC = 8 -> 1 (wave = 32 channels), NWC = 4 -> 2 (wave = 64 channels,
-// one compute wave per SIMD with twice the MFMAs per operand load); the tile width N is the same.
+// out-channel tiles per wave: NWC = 8 -> 1 (wave = 32 channels)
 template <typename DT, int CIN, int NWC>
 using BGeom = BlockGeom<DT, CIN, BlockNT<DT>::NT, NWC, 8 / NWC>;
 
@@ -185,13 +192,11 @@ size_t block_lds(int k) {
     return 2 * (size_t)G::buf_bytes(k, HAS_RES) + (HEAD ? G::HEAD_BYTES : 0);
 }
 
-// One workgroup per CU, 256-column tiles in bf16 and 128 in fp32, as 8 compute waves (wave = 32
-// channels x half the columns) or 4 (wave = 64 channels x half the columns; CAMAL_BLOCK_WAVES).
+// One workgroup per CU: 8 compute waves (wave = 32 channels x half the columns) + the loader wave;
+// 256-column tiles in bf16, 128 in fp32.  0: the tile does not fit the LDS for this first kernel size.
 template <typename DT, int CIN, bool HAS_RES, bool HEAD>
 int block_nwc(size_t lds_per_cu, int k) {
-    static const int want = getenv("CAMAL_BLOCK_WAVES") ? atoi(getenv("CAMAL_BLOCK_WAVES")) : 8;
-    if (block_lds<DT, CIN, 8, HAS_RES, HEAD>(k) > lds_per_cu) return 0;
-    return want == 4 ? 4 : 8;
+    return block_lds<DT, CIN, 8, HAS_RES, HEAD>(k) > lds_per_cu ? 0 : 8;
 }
 
 // can this member's blocks 2/3 run fused (LDS budget depends on the first kernel size)?
@@ -356,7 +361,6 @@ int launch_block(camal_ctx* c, hipStream_t s, const Layer& l1, const Layer& l2, 
                  const void* in, void* out, const float* wfc, float* cam, float* part, int BC, int L,
                  float* cmax = nullptr) {
     const int nwc = block_nwc<DT, CIN, HAS_RES, HEAD>(c->lds_per_cu, l1.ks);
-    if (nwc == 4) return launch_block_w<DT, CIN, 4, HAS_RES, HEAD>(c, s, l1, l2, l3, lr, in, out, wfc, cam, part, BC, L, cmax);
     if (nwc == 8) return launch_block_w<DT, CIN, 8, HAS_RES, HEAD>(c, s, l1, l2, l3, lr, in, out, wfc, cam, part, BC, L, cmax);
     return fail(CAMAL_ERR_ARG, "kernel size too large for the fused block tile");
 }
