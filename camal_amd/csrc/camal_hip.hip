@@ -164,6 +164,7 @@ std::vector<char> pack_weights(const float* w, int cout, int cin, int ks, int pr
 int make_layer(camal_ctx* c, Layer& ly, const float* w, const float* b, int cout, int cin, int ks) {
     ly.cin = cin; ly.cout = cout; ly.ks = ks;
     std::vector<char> p = pack_weights(w, cout, cin, ks, c->precision);
+    p.resize(p.size() + 8192, 0);  // the bf16 weight ring runs 3 groups (6 KiB) past the last out-channel tile's end
     if (int r = upload(c, &ly.wpack, p.data(), p.size())) return r;
     return upload(c, (void**)&ly.bias, b, cout * sizeof(float));
 }
@@ -181,9 +182,9 @@ template <typename DT> struct BlockNT;
 template <> struct BlockNT<float> { static constexpr int NT = 2; };
 template <> struct BlockNT<__bf16> { static constexpr int NT = 4; };
 
-// out-channel tiles per wave: NWC = 8 -> 1 (wave = 32 channels)
+// wave = 32 out-channels x NT column tiles; NWC = 8: two column groups
 template <typename DT, int CIN, int NWC>
-using BGeom = BlockGeom<DT, CIN, BlockNT<DT>::NT, NWC, 8 / NWC>;
+using BGeom = BlockGeom<DT, CIN, BlockNT<DT>::NT, NWC, 1>;
 
 // LDS bytes of one fused-block workgroup
 template <typename DT, int CIN, int NWC, bool HAS_RES, bool HEAD>
@@ -192,8 +193,10 @@ size_t block_lds(int k) {
     return 2 * (size_t)G::buf_bytes(k, HAS_RES) + (HEAD ? G::HEAD_BYTES : 0);
 }
 
-// One workgroup per CU: 8 compute waves (wave = 32 channels x half the columns) + the loader wave;
-// 256-column tiles in bf16, 128 in fp32.  0: the tile does not fit the LDS for this first kernel size.
+// One workgroup per CU: 8 compute waves (wave = 32 channels x half the columns) + the loader wave; 256-column
+// tiles in bf16, 128 in fp32.  0: the tile does not fit the LDS for this first kernel size.
+// (Two 4-wave workgroups of half the tile width per CU, so that one's epilogues and barriers run under the
+// other's MFMAs: measured again on the 16x16x32 kernels, 10 % slower.)
 template <typename DT, int CIN, bool HAS_RES, bool HEAD>
 int block_nwc(size_t lds_per_cu, int k) {
     return block_lds<DT, CIN, 8, HAS_RES, HEAD>(k) > lds_per_cu ? 0 : 8;
@@ -208,7 +211,7 @@ bool fused_fits(const camal_ctx* c, int k) {
 
 template <typename DT>
 int fused_head_tile(size_t lds_per_cu, int k) {
-    return BGeom<DT, C2, 8>::T;  // same tile width for both wave shapes
+    return BGeom<DT, C2, 8>::T;
 }
 
 // timesteps per CAM-head tile (decides the layout of the pooled partial sums)
@@ -330,7 +333,7 @@ int launch_block_w(camal_ctx* c, hipStream_t s, const Layer& l1, const Layer& l2
                    const void* in, void* out, const float* wfc, float* cam, float* part, int BC, int L, float* cmax) {
     constexpr int NTB = BlockNT<DT>::NT;
     using G = BGeom<DT, CIN, NWC>;
-    auto kern = block_kernel<DT, CIN, NTB, NWC, 8 / NWC, HAS_RES, HEAD>;
+    auto kern = block_kernel<DT, CIN, NTB, NWC, 1, HAS_RES, HEAD>;
     const size_t lds = block_lds<DT, CIN, NWC, HAS_RES, HEAD>(l1.ks);
     static size_t attr_set = 0;
     if (lds > attr_set) {
@@ -692,6 +695,15 @@ int camal_nilm_sums(const float* y32, const double* y64, const float* yhat, cons
     HIP_TRY(hipGetLastError());
     return 0;
 }
+
+#ifdef CAMAL_STAMPS
+// diagnostic build only (tools/stamps.py): copies g_stamps [256][9][16] to the host
+int camal_debug_stamps(unsigned long long* out) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(camal::g_stamps), sizeof(unsigned long long) * 256 * 9 * CAMAL_NSTAMP));
+    return 0;
+}
+#endif
 
 int camal_set_profiling(camal_ctx* c, int enabled) {
     if (!c) return fail(CAMAL_ERR_ARG, "null context");

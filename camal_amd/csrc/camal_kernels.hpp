@@ -293,104 +293,120 @@ __device__ __forceinline__ void mma_layer_f32(const char* buf, int Rb, int ks, c
 }
 
 // The same for bf16 on v_mfma_f32_16x16x32_bf16.  K is walked in groups of 32 input channels of one tap
-// (NG = CIN/32 groups per tap); a group takes, per out-channel tile, two A fragments (16 out-channels x 32 k:
-// lane (i = l & 15, q = l >> 4) carries channels 8 kblock(q)..+7 of the group; packed [tap][group][mi][lane][16 B],
-// one coalesced 1 KiB block each) through a ring of 4 groups (3 in flight), and 2 NT B fragments (16 columns x
-// 32 k: lane (i, q) reads the 16-byte chunk 4 group + kblock(q) of row Rb + bcol(i) + tap + 16 f) which rotate
-// through ONE register set: the read for the next group's fragment f is issued right behind this group's
-// MFMAs on fragment f, 14 MFMAs before its use.  Loop body = 4 groups (one tap of 128 channels, two taps of
-// 64), so the ring slots are static; with 64 channels an odd last tap runs as a 2-group tail.
-struct BfRing {
-    const char* buf;
-    const uint4* wp;
-    int R0, q, ks, total;
-    unsigned loff;
-    size_t mstride;
-};
-// group G (ring slot S): issue the loads of group G + 3, wait for this group's fragments, 2 MFMAs per B fragment,
-// each followed by the read of the next group's fragment into the same registers
-template <int CIN, int NT, int MTW, int S>
-__device__ __forceinline__ void bf16_group(const BfRing& r, int G, u32x4 (&a)[4][MTW][2], uint4 (&b)[2 * NT],
-                                           Frag<__bf16> (&acc)[MTW][NT]) {
-    constexpr int RB = CIN * 2, CPR = RB / 16, NG = CIN / 32, AR = 4, NF = 2 * NT;
-    int idx = G + (AR - 1);
-    idx = idx < r.total ? idx : r.total - 1;  // past the end: a repeated load keeps the wait counts uniform
-#pragma unroll
-    for (int m = 0; m < MTW; ++m)
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) w_load(a[(S + AR - 1) % AR][m][mi], r.wp + m * r.mstride + ((size_t)idx * 2 + mi) * 64, r.loff);
-    // the next group's B fragments: same tap, next 32 channels, or the next tap's first (clamped at the end)
-    int Gn = G + 1;
-    Gn = Gn < r.total ? Gn : r.total - 1;
-    const int jn = Gn / NG, gn = Gn - jn * NG;
-    const int rown = r.R0 + jn;
-    const char* rpn = r.buf + rown * RB + (((4 * gn + r.q) ^ swz<CPR>(rown)) << 4);
+// (NG = CIN/32 groups per tap); a group takes two A fragments (16 out-channels x 32 k: lane (i = l & 15,
+// q = l >> 4) carries channels 8 kblock(q)..+7 of the group; packed [tap][group][mi][lane][16 B], 2 KiB per
+// group, consecutive groups consecutive in memory) through a ring of 4 groups (3 in flight), and 2 NT B
+// fragments (16 columns x 32 k: lane (i, q) reads the 16-byte chunk 4 group + kblock(q) of row
+// Rb + bcol(i) + tap + 16 f) which rotate through ONE register set: the read for the next group's fragment f
+// is issued right behind this group's MFMAs on fragment f, 14 MFMAs before its use.
+// Two waves share a SIMD and a 16x16x32 MFMA leaves only 8 issue cycles per MFMA for everything else, so
+// the loop is kept lean: the weight pointer is a scalar that advances by 2 KiB per group (the second
+// fragment through the instruction's offset; no clamp at the end: the ring runs 3 groups past the layer,
+// into the next out-channel tile or the padding make_layer adds), one hand-counted wait per group, and the
+// B address of a tap's later groups is the first one's XOR (group << 6) (swz<> only touches those bits).
+typedef __attribute__((address_space(3))) const u32x4* lds_u4p;
+__device__ __forceinline__ u32x4 lds_read16(unsigned addr) { return *(lds_u4p)(uintptr_t)addr; }
+
+// both fragments of one group; the base goes through s_mov_b64 (see w_load)
+__device__ __forceinline__ void w_load2(u32x4& d0, u32x4& d1, const void* sbase, unsigned lane_off) {
+    unsigned long long tmp;
+    asm volatile("s_mov_b64 %2, %4\n\tglobal_load_dwordx4 %0, %3, %2\n\tglobal_load_dwordx4 %1, %3, %2 offset:1024"
+                 : "=v"(d0), "=v"(d1), "=&s"(tmp)
+                 : "v"(lane_off), "s"(sbase)
+                 : "memory");
+}
+template <int N> __device__ __forceinline__ void w_wait2(u32x4& r0, u32x4& r1) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(N) : "memory");
+}
+
+// group in ring slot S: issue the loads of the group 3 ahead, wait for this group's fragments, 2 MFMAs per B
+// fragment, each followed by the read of the next group's fragment (at LDS address bnext) into the same registers
+template <int RB, int NT, int S>
+__device__ __forceinline__ void bf16_group(const char*& wptr, unsigned loff, unsigned bnext, u32x4 (&a)[4][2],
+                                           u32x4 (&b)[2 * NT], Frag<__bf16> (&acc)[NT]) {
+    constexpr int NF = 2 * NT;
+    w_load2(a[(S + 3) % 4][0], a[(S + 3) % 4][1], wptr, loff);
+    wptr += 2048;
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
         __builtin_amdgcn_sched_barrier(0);
-        if (f == 0)  // this group's weights: all but the AR-1 younger groups' loads have landed
+        if (f == 0) w_wait2<6>(a[S][0], a[S][1]);  // all but the 3 younger groups' loads have landed
 #pragma unroll
-            for (int m = 0; m < MTW; ++m)
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) w_wait<(AR - 1) * 2 * MTW>(a[S][m][mi]);
-#pragma unroll
-        for (int m = 0; m < MTW; ++m)
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-                acc[m][f >> 1].v[2 * mi + (f & 1)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    *reinterpret_cast<const bf16x8*>(&a[S][m][mi]), *reinterpret_cast<const bf16x8*>(&b[f]),
-                    acc[m][f >> 1].v[2 * mi + (f & 1)], 0, 0, 0);
+        for (int mi = 0; mi < 2; ++mi)
+            acc[f >> 1].v[2 * mi + (f & 1)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                *reinterpret_cast<const bf16x8*>(&a[S][mi]), *reinterpret_cast<const bf16x8*>(&b[f]),
+                acc[f >> 1].v[2 * mi + (f & 1)], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        b[f] = *reinterpret_cast<const uint4*>(rpn + f * 16 * RB);
+        b[f] = lds_read16(bnext + f * 16 * RB);
+    }
+}
+
+// LDS address of the lane's chunk of group 0 in row `row` of the tile at LDS address `base`
+template <int RB>
+__device__ __forceinline__ unsigned b_addr(unsigned base, int row, int q) {
+    return base + row * RB + ((q ^ swz<RB / 16>(row)) << 4);
+}
+
+// the NG groups of one tap, first ring slot S0: cur / nxt = b_addr of this tap / of the tap that follows
+template <int CIN, int NT, int S0>
+__device__ __forceinline__ void bf16_tap(const char*& wptr, unsigned loff, unsigned cur, unsigned nxt, u32x4 (&a)[4][2],
+                                         u32x4 (&b)[2 * NT], Frag<__bf16> (&acc)[NT]) {
+    constexpr int RB = CIN * 2, NG = CIN / 32;
+    bf16_group<RB, NT, S0>(wptr, loff, cur ^ (1u << 6), a, b, acc);
+    if constexpr (NG == 2) {
+        bf16_group<RB, NT, S0 + 1>(wptr, loff, nxt, a, b, acc);
+    } else {
+        bf16_group<RB, NT, S0 + 1>(wptr, loff, cur ^ (2u << 6), a, b, acc);
+        bf16_group<RB, NT, S0 + 2>(wptr, loff, cur ^ (3u << 6), a, b, acc);
+        bf16_group<RB, NT, S0 + 3>(wptr, loff, nxt, a, b, acc);
     }
 }
 
 template <int CIN, int NT, int MTW>
-__device__ __forceinline__ void mma_layer_bf16(const char* buf, int Rb, int ks, const uint4* wp, Frag<__bf16> (&acc)[MTW][NT]) {
-    constexpr int RB = CIN * 2, CPR = RB / 16, NG = CIN / 32;
+__device__ __forceinline__ void mma_layer_bf16(const char* buf, int Rb, int ks, const uint4* wp, Frag<__bf16> (&accm)[MTW][NT]) {
+    static_assert(MTW == 1, "one out-channel tile per wave");
+    Frag<__bf16> (&acc)[NT] = accm[0];
+    constexpr int RB = CIN * 2, NG = CIN / 32;
     static_assert(NG == 2 || NG == 4, "64 or 128 input channels");
-    constexpr int TPB = 4 / NG, AR = 4, NF = 2 * NT;
+    constexpr int NF = 2 * NT;
     const int lane = threadIdx.x & 63;
-    BfRing r;
-    r.buf = buf; r.wp = wp; r.ks = ks; r.total = ks * NG;
-    r.R0 = Rb + Frag<__bf16>::bcol(lane);
-    r.q = Frag<__bf16>::kblock(lane);
-    r.loff = lane * 16;
-    r.mstride = (size_t)r.total * 128;
-    u32x4 a[AR][MTW][2];
-    uint4 b[NF];
+    const unsigned loff = lane * 16;
+    const int q = Frag<__bf16>::kblock(lane);
+    const int R0 = Rb + Frag<__bf16>::bcol(lane);
+    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)buf;
+    const char* wptr = reinterpret_cast<const char*>(wp);
+    u32x4 a[4][2];
+    u32x4 b[NF];
 #pragma unroll
-    for (int d = 0; d < AR - 1; ++d)
-#pragma unroll
-        for (int m = 0; m < MTW; ++m)
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-                w_load(a[d][m][mi], wp + m * r.mstride + ((size_t)(d < r.total ? d : r.total - 1) * 2 + mi) * 64, r.loff);
-    {
-        const char* rp = buf + r.R0 * RB + ((r.q ^ swz<CPR>(r.R0)) << 4);
-#pragma unroll
-        for (int f = 0; f < NF; ++f) b[f] = *reinterpret_cast<const uint4*>(rp + f * 16 * RB);
+    for (int d = 0; d < 3; ++d) {
+        w_load2(a[d][0], a[d][1], wptr, loff);
+        wptr += 2048;
     }
-    int G = 0;
-    const int full = (ks / TPB) * 4;  // groups covered by whole loop bodies
+    unsigned cur = b_addr<RB>(base, R0, q);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) b[f] = lds_read16(cur + f * 16 * RB);
+    if constexpr (NG == 4) {
 #pragma unroll 1
-    for (; G < full; G += 4) {
-        bf16_group<CIN, NT, MTW, 0>(r, G, a, b, acc);
-        bf16_group<CIN, NT, MTW, 1>(r, G + 1, a, b, acc);
-        bf16_group<CIN, NT, MTW, 2>(r, G + 2, a, b, acc);
-        bf16_group<CIN, NT, MTW, 3>(r, G + 3, a, b, acc);
+        for (int j = 0; j < ks; ++j) {
+            const unsigned nxt = j + 1 < ks ? b_addr<RB>(base, R0 + j + 1, q) : cur;  // past the end: any valid address
+            bf16_tap<CIN, NT, 0>(wptr, loff, cur, nxt, a, b, acc);
+            cur = nxt;
+        }
+    } else {
+        int j = 0;
+#pragma unroll 1
+        for (; j + 2 <= ks; j += 2) {  // two taps = 4 groups per body: static ring slots
+            const unsigned mid = b_addr<RB>(base, R0 + j + 1, q);
+            const unsigned nxt = j + 2 < ks ? b_addr<RB>(base, R0 + j + 2, q) : mid;
+            bf16_tap<CIN, NT, 0>(wptr, loff, cur, mid, a, b, acc);
+            bf16_tap<CIN, NT, 2>(wptr, loff, mid, nxt, a, b, acc);
+            cur = nxt;
+        }
+        if (j < ks) bf16_tap<CIN, NT, 0>(wptr, loff, cur, cur, a, b, acc);  // the odd last tap
     }
-    if (TPB == 2 && G < r.total) {  // the odd last tap of a 64-channel layer
-        bf16_group<CIN, NT, MTW, 0>(r, G, a, b, acc);
-        bf16_group<CIN, NT, MTW, 1>(r, G + 1, a, b, acc);
-    }
-    // the repeated tail loads are still in flight: nothing may reuse their registers before they land
+    // the ring's last loads (past the layer's end) are still in flight: nothing may reuse their registers before they land
 #pragma unroll
-    for (int d = 0; d < AR; ++d)
-#pragma unroll
-        for (int m = 0; m < MTW; ++m)
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) w_wait<0>(a[d][m][mi]);
+    for (int d = 0; d < 4; ++d) w_wait2<0>(a[d][0], a[d][1]);
 }
 
 // Rb: wave-uniform first row of the wave's columns in the LDS tile (the lane's column is added inside)
@@ -681,6 +697,16 @@ __device__ __forceinline__ void fix_edges(char* buf, int guard, int g, int c_fir
     }
 }
 
+#ifdef CAMAL_STAMPS
+// Diagnostic build only: s_memtime stamps of the second tile of every workgroup (block 3 kernel), per wave.
+#define CAMAL_NSTAMP 16
+__device__ unsigned long long g_stamps[256][9][CAMAL_NSTAMP];
+#define STAMP(i) do { if (HEAD && it == 1 && blockIdx.x < 256 && (threadIdx.x & 63) == 0) \
+    g_stamps[blockIdx.x][threadIdx.x >> 6][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
 struct BlockArgs {
     const void* in;   // [B][L][CIN]
     void* out;        // [B][L][128]   (block 2)
@@ -757,10 +783,11 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
                 stage(tile, Q + xb, pad1, G::xc_bytes());   // centre rows of THIS tile's X (row = column)
                 if (next < a.total_tiles) {
                     stage(next, Q, 0, xb);
-                    // counted wait: the centre rows were issued first and the prefetch is at least 32
-                    // pieces (N rows of >= 128 bytes), so <= 32 outstanding means the centre rows landed
+                    // counted wait: the centre rows were issued first and the prefetch is at least
+                    // N * RBI / 1024 pieces (N rows), so that many outstanding means the centre rows landed
                     // while most of the prefetch stays in flight
-                    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                    constexpr int PF = N * RBI / 1024 > 63 ? 63 : N * RBI / 1024;  // fewer is stricter: still correct
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF) : "memory");
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
@@ -804,28 +831,36 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
 
         F acc[MTW][NT];
         // ---- ConvBlock(k): X(P) -> A1(Q), rows = column + 3
+        STAMP(0);
         zero_acc(acc);
         mma_layer<DT, CIN, NT, MTW>(P, colw, ks1, w1, acc);
+        STAMP(1);
 #pragma unroll
         for (int m = 0; m < MTW; ++m) store_act_lds<DT, NT>(Q, colw + 3, acc[m], a.b1, mt0 + m, opaque(lane));
+        STAMP(2);
         __syncthreads();  // B1
         if (lo || hi) {
             if (wave == 0) fix_edges<DT>(Q, 3, 3, c_first, c_last, lo, hi, lane);
             __syncthreads();
         }
+        STAMP(3);
         // ---- ConvBlock(7): A1(Q) -> A2(P), rows = column + 1
         zero_acc(acc);
         mma_layer<DT, 128, NT, MTW>(Q, colw, 7, w2, acc);
+        STAMP(4);
 #pragma unroll
         for (int m = 0; m < MTW; ++m) store_act_lds<DT, NT>(P, colw + 1, acc[m], a.b2, mt0 + m, opaque(lane));
+        STAMP(5);
         __syncthreads();  // B2
         if (lo || hi) {
             if (wave == 0) fix_edges<DT>(P, 1, 1, c_first, c_last, lo, hi, lane);
             __syncthreads();
         }
+        STAMP(6);
         // ---- ConvBlock(3): A2(P) -> registers
         zero_acc(acc);
         mma_layer<DT, 128, NT, MTW>(P, colw, 3, w3, acc);
+        STAMP(7);
 
         float bv[4][4];
         const int le = opaque(lane);  // epilogue addresses are computed here, not once per kernel
@@ -939,7 +974,9 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
                 if (a.cmax != nullptr && pm > 0.f) atomicMax(reinterpret_cast<unsigned int*>(a.cmax) + b, __float_as_uint(pm));
             }
         }
+        STAMP(8);
         __syncthreads();  // END
+        STAMP(9);
     }
 }
 

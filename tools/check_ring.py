@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Static check of the hand-counted weight ring (camal_kernels.hpp: w_load / w_wait) in the device assembly.
+
+The ring's loads are inline asm: hipcc believes their destination registers are written at the asm
+statement, while the data lands later (before the matching hand-placed s_waitcnt).  If the compiler
+copies, spills or overwrites such a register between the load and its first consumer, the result is a
+silent wrong value or, worse, a late write into a register that meanwhile holds something else.
+This script walks every kernel of `hipcc -S --cuda-device-only` output and reports any non-asm
+instruction that touches a register with a ring load in flight, other than the MFMA that consumes it.
+It also reports an asm load whose SGPR base is not produced by the s_mov_b64 in front of it
+(VALU-writes-SGPR -> VMEM hazard).   usage: check_ring.py file.s   -> exit status 1 on findings
+"""
+import re
+import sys
+
+
+def regs(tok):
+    out = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", tok):
+        out.update(range(int(a), int(b) + 1))
+    for a in re.findall(r"\bv(\d+)\b", tok):
+        out.add(int(a))
+    return out
+
+
+def check(path):
+    findings = []
+    kernel, pending, inasm, prev = None, set(), False, ""
+    for n, line in enumerate(open(path), 1):
+        t = line.strip()
+        if t.startswith(".amdhsa_kernel") or (t.endswith(":") and t.startswith("_Z") and "camal" in t):
+            if t.endswith(":"):
+                kernel, pending = t[:-1], set()
+            continue
+        if "ASMSTART" in t:
+            inasm = True
+            continue
+        if "ASMEND" in t:
+            inasm = False
+            continue
+        if not t or t.startswith(";") or t.startswith("."):
+            continue
+        if inasm:
+            if t.startswith("global_load_dwordx4"):
+                pending |= regs(t.split(",")[0])
+                sb = t.split(",")[2].split()[0]
+                if not (prev.startswith("s_mov_b64") or (prev.startswith("global_load_dwordx4") and sb in prev)):
+                    findings.append((kernel, n, "asm load without s_mov_b64 in front: " + t))
+            elif t.startswith("s_waitcnt vmcnt(0)"):
+                pending = set()
+            prev = t
+            continue
+        prev = t
+        if not pending:
+            continue
+        touched = regs(t) & pending
+        if not touched:
+            continue
+        if t.startswith("v_mfma"):
+            # consumer: A operand (second register tuple) = ring registers; they are free afterwards
+            ops = [o.strip() for o in t.split(None, 1)[1].split(",")]
+            pending -= regs(ops[1])
+            bad = (regs(ops[0]) | regs(ops[2]) | regs(ops[3] if len(ops) > 3 else "")) & pending
+            if bad:
+                findings.append((kernel, n, "MFMA touches in-flight ring registers as non-A operand: " + t))
+            continue
+        findings.append((kernel, n, "touches in-flight ring registers %s: %s" % (sorted(touched)[:4], t)))
+    return findings
+
+
+if __name__ == "__main__":
+    f = check(sys.argv[1])
+    for k, n, msg in f[:40]:
+        print(f"{k}:{n}: {msg}")
+    print(f"{len(f)} finding(s)")
+    sys.exit(1 if f else 0)
