@@ -190,7 +190,7 @@ using BGeom = BlockGeom<DT, CIN, BlockNT<DT>::NT, NWC, 1>;
 template <typename DT, int CIN, int NWC, bool HAS_RES, bool HEAD>
 size_t block_lds(int k) {
     using G = BGeom<DT, CIN, NWC>;
-    return 2 * (size_t)G::buf_bytes(k, HAS_RES) + (HEAD ? G::HEAD_BYTES : 0);
+    return 2 * (size_t)G::buf_bytes(k, HAS_RES) + (HEAD ? G::HEAD_BYTES : 0) + G::CST_FLOATS * sizeof(float);
 }
 
 // One workgroup per CU: 8 compute waves (wave = 32 channels x half the columns) + the loader wave; 256-column

@@ -651,26 +651,53 @@ __global__ __launch_bounds__((NWC + 1) * 64) void conv_kernel(const DT* __restri
 //     rectified accumulator, so no second accumulator is needed.
 //   HEAD (block 3): CAM head as in conv_kernel; the 128 x L feature map is never written.
 // ---------------------------------------------------------------------------------------
-// relu(acc + bias) of this wave's 32-channel x NT*32-column tile -> CH-channel LDS rows; row0 = LDS row of the
-// wave's first column (wave-uniform), bias = the layer's bias vector
-template <typename DT, int NT, int CH = 128>
-__device__ __forceinline__ void store_act_lds(char* dst, int row0, const Frag<DT> (&acc)[NT], const float* __restrict__ bias,
-                                              int mt, int lane) {
+// relu of 4 values, stored in the activation type.  bf16: round first, then clamp the packed pairs as signed
+// 16-bit integers (a negative bf16 is a negative int16; -0 and negative NaNs become +0 like everything below 0)
+__device__ __forceinline__ void store4_relu(float* p, float a, float b, float c, float d) {
+    store4(p, fmaxf(a, 0.f), fmaxf(b, 0.f), fmaxf(c, 0.f), fmaxf(d, 0.f));
+}
+__device__ __forceinline__ void store4_relu(__bf16* p, float a, float b, float c, float d) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+    s16x4 w = __builtin_bit_cast(s16x4, v);
+    const s16x4 z = {0, 0, 0, 0};
+    w = __builtin_elementwise_max(w, z);
+    *reinterpret_cast<s16x4*>(p) = w;
+}
+
+// The accumulators of a layer start from its (BN-folded) bias, read from the LDS copy `cst` of the bias vector:
+// the epilogue is then a bare relu, and no vector-memory load sits between a K loop and its epilogue.
+template <typename DT, int NT>
+__device__ __forceinline__ void init_acc_bias(Frag<DT> (&acc)[NT], const float* cst, int mt, int lane) {
     using F = Frag<DT>;
-    constexpr int RB = CH * (int)sizeof(DT), CPR = RB / 16;
     float bv[4][4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) load4(bias + 32 * mt + F::chan(g, lane), bv[g]);
+    for (int g = 0; g < 4; ++g) load4(cst + 32 * mt + F::chan(g, lane), bv[g]);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int row = row0 + nt * 32 + F::col(g, lane);
-            const int boff = (32 * mt + F::chan(g, lane)) * (int)sizeof(DT);
-            DT* p = reinterpret_cast<DT*>(dst + row * RB + (((boff >> 4) ^ swz<CPR>(row)) << 4) + (boff & 15));
-            store4(p, fmaxf(acc[nt].get(g, 0) + bv[g][0], 0.f), fmaxf(acc[nt].get(g, 1) + bv[g][1], 0.f),
-                   fmaxf(acc[nt].get(g, 2) + bv[g][2], 0.f), fmaxf(acc[nt].get(g, 3) + bv[g][3], 0.f));
-        }
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[nt].set(g, i, bv[g][i]);
+}
+
+// relu(acc) of this wave's 32-channel x NT*32-column tile -> CH-channel LDS rows; row0 = LDS row of the wave's
+// first column (wave-uniform).  One address per group g (swz<> of a row does not change when 16 or 32 rows are
+// added, so the column tiles are constant offsets from it).
+template <typename DT, int NT, int CH = 128>
+__device__ __forceinline__ void store_act_lds(char* dst, int row0, const Frag<DT> (&acc)[NT], int mt, int lane) {
+    using F = Frag<DT>;
+    constexpr int RB = CH * (int)sizeof(DT), CPR = RB / 16;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int row = row0 + F::col(g, lane);
+        const int boff = (32 * mt + F::chan(g, lane)) * (int)sizeof(DT);
+        char* pg = dst + row * RB + (((boff >> 4) ^ swz<CPR>(row)) << 4) + (boff & 15);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            store4_relu(reinterpret_cast<DT*>(pg + nt * 32 * RB), acc[nt].get(g, 0), acc[nt].get(g, 1), acc[nt].get(g, 2),
+                        acc[nt].get(g, 3));
+    }
 }
 
 // rows just outside the window take the edge row's values (replicate padding of THIS layer's output)
@@ -728,6 +755,7 @@ struct BlockGeom {
     static constexpr int RBI = CIN * ES;       // X row bytes
     static constexpr int RBA = 128 * ES;       // A1 / A2 row bytes
     static constexpr int HEAD_BYTES = (4 * N * 2 + 3 * NWC) * 4;
+    static constexpr int CST_FLOATS = 5 * 128;  // LDS copies of b1, b2, b3 and (br | the two head rows)
     __host__ __device__ static constexpr int x_bytes(int ks) { return (((N + ks - 1) * RBI) + 1023) & ~1023; }
     __host__ __device__ static constexpr int xc_bytes() { return ((N * RBI) + 1023) & ~1023; }
     // one buffer must hold X, or A1 (N + 6 rows), or [next X | centre rows of X] (HAS_RES)
@@ -749,7 +777,16 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
     const int bufb = G::buf_bytes(ks1, HAS_RES);
     const int xb = G::x_bytes(ks1);
     float* red = reinterpret_cast<float*>(lds + 2 * bufb);
+    float* cst = reinterpret_cast<float*>(lds + 2 * bufb + (HEAD ? G::HEAD_BYTES : 0));  // [5][128]
     const int tpw = a.tiles_per_window;
+    if (threadIdx.x < 128) {  // visible after the barrier that publishes the first X tile
+        const int i = threadIdx.x;
+        cst[i] = a.b1[i];
+        cst[128 + i] = a.b2[i];
+        cst[256 + i] = a.b3[i];
+        if (HEAD) { cst[384 + i] = a.wfc[i]; cst[512 + i] = a.wfc[128 + i]; }
+        else if (HAS_RES) cst[384 + i] = a.br[i];
+    }
 
     if (wave == NWC) {
         // ------------------------------ loader wave ------------------------------------
@@ -796,8 +833,44 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
                 stage(next, Q, 0, xb);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (HEAD) { __syncthreads(); __syncthreads(); }
-            __syncthreads();                       // END: next X landed
+            __syncthreads();                       // END: next X landed (HEAD: and the CAM partials are in `red`)
+            if constexpr (HEAD) {
+                // Second half of the CAM head, off the compute waves' critical path (they are already in the
+                // next tile's first K loop; `red` is not written again before three more barriers that this
+                // wave joins): per column the sum of the 4 channel tiles' partial dot products = the two CAM
+                // rows' values; the row asked for goes out, both rows' tile sums (for the logits) and the
+                // tile maximum of the clipped CAM (core.py:311) follow by a fixed shuffle tree.
+                float s0 = 0.f, s1 = 0.f, mx = 0.f;
+                for (int c = lane; c < N; c += 64) {
+                    float c0 = 0.f, c1 = 0.f;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        c0 += red[(m * N + c) * 2 + 0];
+                        c1 += red[(m * N + c) * 2 + 1];
+                    }
+                    const int p = t0 - 4 + c;
+                    if (c >= 4 && c < 4 + T && p < L) {
+                        const float cv = a.cam_row ? c1 : c0;
+                        a.cam[(size_t)b * L + p] = cv;
+                        mx = fmaxf(mx, clip_cam(cv));
+                        s0 += c0;
+                        s1 += c1;
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    s0 += __shfl_xor(s0, o);
+                    s1 += __shfl_xor(s1, o);
+                    mx = fmaxf(mx, __shfl_xor(mx, o));
+                }
+                if (lane == 0) {
+                    float* po = a.part + ((size_t)b * tpw + (tile - b * tpw)) * 2;
+                    po[0] = s0;
+                    po[1] = s1;
+                    // non-negative floats order like their bit patterns
+                    if (a.cmax != nullptr && mx > 0.f) atomicMax(reinterpret_cast<unsigned int*>(a.cmax) + b, __float_as_uint(mx));
+                }
+            }
         }
         return;
     }
@@ -813,11 +886,9 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
     const uint4* w1 = a.w1 + (size_t)mt0 * ks1 * NCPI * 64;
     const uint4* w2 = a.w2 + (size_t)mt0 * 7 * NCPA * 64;
     const uint4* w3 = a.w3 + (size_t)mt0 * 3 * NCPA * 64;
-    auto zero_acc = [&](F (&acc)[MTW][NT]) {
+    auto start_acc = [&](F (&acc)[MTW][NT], int layer) {  // accumulators = the layer's bias
 #pragma unroll
-        for (int m = 0; m < MTW; ++m)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[m][nt].zero();
+        for (int m = 0; m < MTW; ++m) init_acc_bias<DT, NT>(acc[m], cst + 128 * layer, mt0 + m, lane);
     };
 
     __syncthreads();  // first X landed
@@ -832,11 +903,11 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
         F acc[MTW][NT];
         // ---- ConvBlock(k): X(P) -> A1(Q), rows = column + 3
         STAMP(0);
-        zero_acc(acc);
+        start_acc(acc, 0);
         mma_layer<DT, CIN, NT, MTW>(P, colw, ks1, w1, acc);
         STAMP(1);
 #pragma unroll
-        for (int m = 0; m < MTW; ++m) store_act_lds<DT, NT>(Q, colw + 3, acc[m], a.b1, mt0 + m, opaque(lane));
+        for (int m = 0; m < MTW; ++m) store_act_lds<DT, NT>(Q, colw + 3, acc[m], mt0 + m, opaque(lane));
         STAMP(2);
         __syncthreads();  // B1
         if (lo || hi) {
@@ -845,11 +916,11 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
         }
         STAMP(3);
         // ---- ConvBlock(7): A1(Q) -> A2(P), rows = column + 1
-        zero_acc(acc);
+        start_acc(acc, 1);
         mma_layer<DT, 128, NT, MTW>(Q, colw, 7, w2, acc);
         STAMP(4);
 #pragma unroll
-        for (int m = 0; m < MTW; ++m) store_act_lds<DT, NT>(P, colw + 1, acc[m], a.b2, mt0 + m, opaque(lane));
+        for (int m = 0; m < MTW; ++m) store_act_lds<DT, NT>(P, colw + 1, acc[m], mt0 + m, opaque(lane));
         STAMP(5);
         __syncthreads();  // B2
         if (lo || hi) {
@@ -858,25 +929,23 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
         }
         STAMP(6);
         // ---- ConvBlock(3): A2(P) -> registers
-        zero_acc(acc);
+        start_acc(acc, 2);
         mma_layer<DT, 128, NT, MTW>(P, colw, 3, w3, acc);
         STAMP(7);
 
         float bv[4][4];
         const int le = opaque(lane);  // epilogue addresses are computed here, not once per kernel
         if constexpr (!HEAD) {
-            // relu(conv3 + b3) in registers, then the 1x1 skip accumulates on top by MFMA
+            // relu(conv3 + b3) in registers (the bias came in with the accumulator), then the 1x1 skip
+            // accumulates on top by MFMA
 #pragma unroll
-            for (int m = 0; m < MTW; ++m) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) load4(a.b3 + 32 * (mt0 + m) + F::chan(g, le), bv[g]);
+            for (int m = 0; m < MTW; ++m)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) acc[m][nt].set(g, i, fmaxf(acc[m][nt].get(g, i) + bv[g][i], 0.f));
-            }
+                        for (int i = 0; i < 4; ++i) acc[m][nt].set(g, i, fmaxf(acc[m][nt].get(g, i), 0.f));
             if constexpr (HAS_RES) {
                 __syncthreads();  // BR: centre rows of X landed in Q + xb
                 const uint4* wr = a.wr + (size_t)mt0 * NCPI * 64;
@@ -888,7 +957,7 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
                 const int mt = mt0 + m;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    if (HAS_RES) load4(a.br + 32 * mt + F::chan(g, le), bv[g]);
+                    if (HAS_RES) load4(cst + 384 + 32 * mt + F::chan(g, le), bv[g]);
                     else bv[g][0] = bv[g][1] = bv[g][2] = bv[g][3] = 0.f;
                 }
 #pragma unroll
@@ -909,9 +978,8 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
                 float w0[4][4], w1v[4][4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    load4(a.b3 + 32 * mt + F::chan(g, le), bv[g]);
-                    load4(a.wfc + 32 * mt + F::chan(g, le), w0[g]);
-                    load4(a.wfc + 128 + 32 * mt + F::chan(g, le), w1v[g]);
+                    load4(cst + 384 + 32 * mt + F::chan(g, le), w0[g]);
+                    load4(cst + 512 + 32 * mt + F::chan(g, le), w1v[g]);
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
@@ -922,7 +990,7 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
                     for (int g = 0; g < 4; ++g)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            const float f = fmaxf(acc[m][nt].get(g, i) + bv[g][i], 0.f);
+                            const float f = fmaxf(acc[m][nt].get(g, i), 0.f);
                             c0[F::colslot(g)] = fmaf(w0[g][i], f, c0[F::colslot(g)]);
                             c1[F::colslot(g)] = fmaf(w1v[g][i], f, c1[F::colslot(g)]);
                         }
@@ -937,42 +1005,7 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
                     }
                 }
             }
-            __syncthreads();
-            float s0 = 0.f, s1 = 0.f, mx = 0.f;
-            for (int c = threadIdx.x; c < N; c += NWC * 64) {
-                float c0 = 0.f, c1 = 0.f;
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    c0 += red[(m * N + c) * 2 + 0];
-                    c1 += red[(m * N + c) * 2 + 1];
-                }
-                const int p = t0 - 4 + c;
-                if (c >= 4 && c < 4 + T && p < L) {
-                    const float cv = a.cam_row ? c1 : c0;
-                    a.cam[(size_t)b * L + p] = cv;
-                    mx = fmaxf(mx, clip_cam(cv));
-                    s0 += c0;
-                    s1 += c1;
-                }
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                s0 += __shfl_xor(s0, o);
-                s1 += __shfl_xor(s1, o);
-                mx = fmaxf(mx, __shfl_xor(mx, o));
-            }
-            float* red2 = red + 4 * N * 2;
-            if (lane == 0) { red2[3 * wave] = s0; red2[3 * wave + 1] = s1; red2[3 * wave + 2] = mx; }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                float p0 = 0.f, p1 = 0.f, pm = 0.f;
-#pragma unroll
-                for (int wv = 0; wv < NWC; ++wv) { p0 += red2[3 * wv]; p1 += red2[3 * wv + 1]; pm = fmaxf(pm, red2[3 * wv + 2]); }
-                float* po = a.part + ((size_t)b * tpw + tx) * 2;
-                po[0] = p0;
-                po[1] = p1;
-                if (a.cmax != nullptr && pm > 0.f) atomicMax(reinterpret_cast<unsigned int*>(a.cmax) + b, __float_as_uint(pm));
-            }
+            // the loader wave finishes the head behind the END barrier (sums over channel tiles, CAM row, tile sums)
         }
         STAMP(8);
         __syncthreads();  // END
@@ -1012,7 +1045,8 @@ struct Block1Geom {
     static constexpr int XS = N + 64;               // floats per x buffer (N + k - 1 <= N + 62)
     static constexpr int A1_BYTES = (((N + 6) * RB) + 1023) & ~1023;
     static constexpr int A2_BYTES = (((N + 2) * RB) + 1023) & ~1023;
-    static constexpr int LDS_BYTES = A1_BYTES + A2_BYTES + 2 * XS * 4;
+    static constexpr int CST_OFF = A1_BYTES + A2_BYTES + 2 * XS * 4;  // LDS copies of b2, b3, wr, br: [4][64] floats
+    static constexpr int LDS_BYTES = CST_OFF + 4 * 64 * 4;
 };
 
 template <typename DT, int NT>
@@ -1036,6 +1070,14 @@ __global__ __launch_bounds__(512) void block1_kernel(Block1Args a, const float* 
         p = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
         return a.x[(size_t)b * L + p];
     };
+    float* cst = reinterpret_cast<float*>(lds + G::CST_OFF);
+    if (threadIdx.x < 64) {  // visible after the barrier below
+        const int i = threadIdx.x;
+        cst[i] = a.b2[i];
+        cst[64 + i] = a.b3[i];
+        cst[128 + i] = res_w[i];
+        cst[192 + i] = res_b[i];
+    }
     constexpr int XPT = (G::XS + 511) / 512;  // x values per thread
     if ((int)blockIdx.x < a.total_tiles)
 #pragma unroll
@@ -1106,30 +1148,25 @@ __global__ __launch_bounds__(512) void block1_kernel(Block1Args a, const float* 
             __syncthreads();
         }
         F acc[1][NT];
-        auto zero_acc = [&]() {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[0][nt].zero();
-        };
-        // ---- ConvBlock(7): A1 -> A2, rows = column + 1
-        zero_acc();
+        // ---- ConvBlock(7): A1 -> A2, rows = column + 1   (accumulators start from the bias)
+        init_acc_bias<DT, NT>(acc[0], cst, mt, lane);
         mma_layer<DT, 64, NT, 1>(A1, colw, 7, w2, acc);
-        store_act_lds<DT, NT, 64>(A2, colw + 1, acc[0], a.b2, mt, opaque(lane));
+        store_act_lds<DT, NT, 64>(A2, colw + 1, acc[0], mt, opaque(lane));
         __syncthreads();
         if (lo || hi) {
             if (wave == 0) fix_edges<DT, 64>(A2, 1, 1, c_first, c_last, lo, hi, lane);
             __syncthreads();
         }
         // ---- ConvBlock(3): A2 -> registers; out = relu(. + b3) + (wr x + br)   (skip added after the ReLU)
-        zero_acc();
+        init_acc_bias<DT, NT>(acc[0], cst + 64, mt, lane);
         mma_layer<DT, 64, NT, 1>(A2, colw, 3, w3, acc);
         {
-            float bv[4][4], wr[4][4], br[4][4];
+            float wr[4][4], br[4][4];
             const int le = opaque(lane);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                load4(a.b3 + 32 * mt + F::chan(g, le), bv[g]);
-                load4(res_w + 32 * mt + F::chan(g, le), wr[g]);
-                load4(res_b + 32 * mt + F::chan(g, le), br[g]);
+                load4(cst + 128 + 32 * mt + F::chan(g, le), wr[g]);
+                load4(cst + 192 + 32 * mt + F::chan(g, le), br[g]);
             }
             DT* outp = reinterpret_cast<DT*>(a.out);
 #pragma unroll
@@ -1142,8 +1179,7 @@ __global__ __launch_bounds__(512) void block1_kernel(Block1Args a, const float* 
                         const float xv = xc[c + pad1];
                         float v[4];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            v[i] = fmaxf(acc[0][nt].get(g, i) + bv[g][i], 0.f) + fmaf(wr[g][i], xv, br[g][i]);
+                        for (int i = 0; i < 4; ++i) v[i] = fmaxf(acc[0][nt].get(g, i), 0.f) + fmaf(wr[g][i], xv, br[g][i]);
                         store4(outp + ((size_t)b * L + p) * 64 + 32 * mt + F::chan(g, le), v[0], v[1], v[2], v[3]);
                     }
                 }

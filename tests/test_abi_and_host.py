@@ -156,3 +156,23 @@ def test_nilm_to_clf_labels():
     d[1, 1, 1, 2] = 1
     X, y = nilmdataset_to_clfdataset(d)
     assert X.shape == (3, 5) and list(y) == [0, 1, 0]
+
+
+def test_hand_counted_weight_ring_is_untouched_by_the_compiler(tmp_path):
+    """tools/check_ring.py on the device assembly: no compiler-made instruction may touch a register that a
+    hand-issued weight load (inline asm, landing asynchronously) still has in flight, and every such load takes
+    its scalar base through the s_mov_b64 in front of it (VALU-writes-SGPR -> VMEM hazard)."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc here")
+    asm = tmp_path / "camal.s"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", str(asm),
+                           os.path.join(ROOT, "camal_amd", "csrc", "camal_hip.hip")], stderr=subprocess.DEVNULL)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_ring
+    text = asm.read_text()
+    assert text.count("ASMSTART") > 100 and "v_mfma_f32_16x16x32_bf16" in text
+    assert check_ring.check(str(asm)) == []
