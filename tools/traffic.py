@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def kernel_class(name):
     if "post_kernel" in name:
         return "post"
-    if "conv_kernel" in name or "block_kernel" in name:
+    if "conv_kernel" in name or "block_kernel" in name or "block1_kernel" in name:
         return "conv"
     if "stem_kernel" in name:
         return "stem"
