@@ -173,6 +173,7 @@ int make_layer(camal_ctx* c, Layer& ly, const float* w, const float* b, int cout
 struct Workspace {
     void *a1, *b1, *r1, *a2, *b2, *r2;
     float *cam, *part, *logits, *cmax;
+    double* hdr;
     int ntiles;
 };
 
@@ -237,7 +238,8 @@ size_t workspace_layout(const camal_ctx* c, int BC, int PB, int L, Workspace* w,
     t.a1 = take(n64); t.b1 = take(n64); t.r1 = take(n64);
     t.a2 = take(n128); t.b2 = take(n128); t.r2 = take(n128);
     t.cam = (float*)take(align_up((size_t)c->E * PB * L * 4));
-    t.part = (float*)take(align_up((size_t)BC * ntiles * 2 * 4));
+    t.part = (float*)take(align_up((size_t)c->E * PB * ntiles * 2 * 4));  // [E][PB][ntiles][2]
+    t.hdr = (double*)take(align_up((size_t)PB * (c->E + 1) * 8));
     t.logits = (float*)take(align_up((size_t)c->E * PB * 2 * 4));
     t.cmax = (float*)take(align_up((size_t)c->E * PB * 4));
     t.ntiles = ntiles;
@@ -434,11 +436,18 @@ int run_member(camal_ctx* c, hipStream_t s, const Member& m, const float* x, int
     return 0;
 }
 
+// pooled-sum tiles per window of member m's CAM head
+int member_ntiles(const camal_ctx* c, const Member& m, int L) {
+    const int tl = head_tile_len(c, c->fused && fused_fits(c, m.k), m.k);
+    return (L + tl - 1) / tl;
+}
+
+// logits == nullptr: the caller finalizes the pooled sums itself (camal_localize: header_kernel)
 int run_member_any(camal_ctx* c, hipStream_t s, const Member& m, const float* x, int BC, int L, const Workspace& w,
                    float* cam, float* part, float* logits, float* cmax) {
     int r = c->precision == CAMAL_FP32 ? run_member<float>(c, s, m, x, BC, L, w, cam, part, cmax)
                                        : run_member<__bf16>(c, s, m, x, BC, L, w, cam, part, cmax);
-    if (r) return r;
+    if (r || !logits) return r;
     ProfScope ps(c, s, 4);
     const int tl = head_tile_len(c, c->fused && fused_fits(c, m.k), m.k);
     hipLaunchKernelGGL(logits_kernel, dim3((BC + 127) / 128), dim3(128), 0, s, part, m.bfc, logits, BC, (L + tl - 1) / tl, L);
@@ -455,23 +464,34 @@ int check_ctx(camal_ctx* c, int B, int L) {
     return 0;
 }
 
-// own_max: the rows' maxima are not in a.cmax; the kernel scans the rows for them
+bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// own_max: no header_kernel ran; the kernel derives the votes and scans the rows for their maxima
 int launch_post(camal_ctx* c, hipStream_t s, const PostArgs& a0, bool own_max) {
     ProfScope ps(c, s, 3);
     const int tiles = (a0.L + POST_TILE - 1) / POST_TILE;
     constexpr int kMaxY = 32768;  // grid.y limit is 65535
+    // 16-byte accesses when every row of every array starts on a 16-byte boundary
+    const bool vec = a0.L % 4 == 0 && aligned16(a0.cam) && a0.cam_estride % 4 == 0 && aligned16(a0.x) && aligned16(a0.state_out) &&
+                     aligned16(a0.avg_out) && aligned16(a0.power_out);
     for (int b0 = 0; b0 < a0.B; b0 += kMaxY) {
         PostArgs a = a0;
         const size_t o = (size_t)b0 * a0.L;
         a.B = std::min(kMaxY, a0.B - b0);
-        a.cam += o; a.logits += 2 * (size_t)b0; if (a.cmax) a.cmax += b0;
+        a.cam += o; if (a.logits) a.logits += 2 * (size_t)b0; if (a.hdr) a.hdr += (size_t)b0 * (a0.E + 1);
         a.x += o; if (a.x64) a.x64 += o; if (a.y) a.y += b0;
-        a.prob_out += b0; a.state_out += o; if (a.avg_out) a.avg_out += o; if (a.power_out) a.power_out += o;
+        if (a.prob_out) a.prob_out += b0;
+        a.state_out += o; if (a.avg_out) a.avg_out += o; if (a.power_out) a.power_out += o;
         const dim3 grid(tiles, a.B), block(256);
         // 4 members per load round: 5 or 8 per round cost more registers (occupancy) than the round trip
-        // they save (measured on E = 5: 44.7 us with 4, 45.7 with 5, 53.9 with 8, per 4096 x 1440 launch)
-        if (own_max) hipLaunchKernelGGL((post_kernel<true, 4>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((post_kernel<false, 4>), grid, block, 0, s, a);
+        // they save (measured on E = 5)
+        if (own_max) {
+            if (vec) hipLaunchKernelGGL((post_kernel<true, 4, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((post_kernel<true, 4, false>), grid, block, 0, s, a);
+        } else {
+            if (vec) hipLaunchKernelGGL((post_kernel<false, 4, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((post_kernel<false, 4, false>), grid, block, 0, s, a);
+        }
         HIP_TRY(hipGetLastError());
     }
     return 0;
@@ -604,8 +624,8 @@ int camal_postprocess(int E, const float* cam, const float* logits, const float*
     if (B < 1 || L < 1) return fail(CAMAL_ERR_ARG, "B and L must be >= 1");
     if (w_ma < 1 || w_ma > 64) return fail(CAMAL_ERR_ARG, "w_ma must be in 1..64");
     PostArgs a;
-    a.cam = cam; a.logits = logits; a.cmax = nullptr; a.x = x; a.x64 = x64; a.y = y;
-    a.cam_estride = (size_t)B * L; a.lg_estride = (size_t)B * 2; a.cmax_estride = 0;
+    a.cam = cam; a.logits = logits; a.hdr = nullptr; a.x = x; a.x64 = x64; a.y = y;
+    a.cam_estride = (size_t)B * L; a.lg_estride = (size_t)B * 2;
     a.prob_out = prob_out; a.avg_out = avg_cam_out; a.state_out = state_out; a.power_out = power_out;
     a.E = E; a.B = B; a.L = L; a.w_ma = w_ma; a.gate_mode = gate_mode; a.pred_f64 = pred_f64;
     a.p_on = p_on; a.scale_mul = scale_mul; a.scale_add = scale_add;
@@ -634,25 +654,41 @@ int camal_localize(camal_ctx* c, const float* x, const double* x64, const int8_t
         // wait in the workspace as [E][ng][..]
         const int ng = std::min(PB, B - g0);
         HIP_TRY(hipMemsetAsync(w.cmax, 0, (size_t)E * ng * 4, s));
+        HeaderArgs h;
         for (int c0 = g0; c0 < g0 + ng; c0 += BC) {
             const int n = std::min(BC, g0 + ng - c0);
             for (int e = 0; e < E; ++e) {
+                const int nt = member_ntiles(c, c->m[e], L);
                 float* camw = w.cam + ((size_t)e * ng + (c0 - g0)) * L;
-                float* lgw = w.logits + ((size_t)e * ng + (c0 - g0)) * 2;
+                // member stride ng * w.ntiles * 2 (upper bound), window stride = the member's own tile count
+                float* partw = w.part + (size_t)e * ng * w.ntiles * 2 + (size_t)(c0 - g0) * nt * 2;
                 float* cmw = w.cmax + (size_t)e * ng + (c0 - g0);
-                if (int r = run_member_any(c, s, c->m[e], x + (size_t)c0 * L, n, L, w, camw, w.part, lgw, cmw)) return r;
-                if (member_logits_out)
-                    HIP_TRY(hipMemcpyAsync(member_logits_out + ((size_t)e * B + c0) * 2, lgw, (size_t)n * 2 * 4, hipMemcpyDeviceToDevice, s));
+                if (int r = run_member_any(c, s, c->m[e], x + (size_t)c0 * L, n, L, w, camw, partw, nullptr, cmw)) return r;
                 if (member_cam_out)
                     HIP_TRY(hipMemcpyAsync(member_cam_out + ((size_t)e * B + c0) * L, camw, (size_t)n * L * 4, hipMemcpyDeviceToDevice, s));
             }
         }
+        // one header launch per group: logits, votes, per-member 1/max
+        h.part = w.part; h.cmax = w.cmax; h.logits = w.logits;
+        h.part_estride = (size_t)ng * w.ntiles * 2; h.cmax_estride = (size_t)ng; h.lg_estride = (size_t)ng * 2;
+        for (int e = 0; e < E; ++e) { h.bfc[e] = c->m[e].bfc; h.ntiles[e] = member_ntiles(c, c->m[e], L); }
+        h.y = y ? y + g0 : nullptr;
+        h.prob_out = prob_out + g0; h.hdr = w.hdr;
+        h.E = E; h.B = ng; h.L = L; h.gate_mode = gate_mode;
+        {
+            ProfScope ps(c, s, 4);
+            hipLaunchKernelGGL(header_kernel, dim3((ng + 127) / 128), dim3(128), 0, s, h);
+            HIP_TRY(hipGetLastError());
+        }
+        if (member_logits_out)
+            for (int e = 0; e < E; ++e)
+                HIP_TRY(hipMemcpyAsync(member_logits_out + ((size_t)e * B + g0) * 2, w.logits + (size_t)e * ng * 2, (size_t)ng * 2 * 4, hipMemcpyDeviceToDevice, s));
         PostArgs a;
-        a.cam = w.cam; a.logits = w.logits; a.cmax = w.cmax;
-        a.cam_estride = (size_t)ng * L; a.lg_estride = (size_t)ng * 2; a.cmax_estride = (size_t)ng;
+        a.cam = w.cam; a.logits = nullptr; a.hdr = w.hdr;
+        a.cam_estride = (size_t)ng * L; a.lg_estride = 0;
         a.x = x + (size_t)g0 * L; a.x64 = x64 ? x64 + (size_t)g0 * L : nullptr;
-        a.y = y ? y + g0 : nullptr;
-        a.prob_out = prob_out + g0; a.avg_out = avg_cam_out ? avg_cam_out + (size_t)g0 * L : nullptr;
+        a.y = nullptr;
+        a.prob_out = nullptr; a.avg_out = avg_cam_out ? avg_cam_out + (size_t)g0 * L : nullptr;
         a.state_out = state_out + (size_t)g0 * L; a.power_out = power_out ? power_out + (size_t)g0 * L : nullptr;
         a.E = E; a.B = ng; a.L = L; a.w_ma = w_ma; a.gate_mode = gate_mode; a.pred_f64 = pred_f64;
         a.p_on = p_on; a.scale_mul = scale_mul; a.scale_add = scale_add;

@@ -1230,19 +1230,71 @@ __global__ void logits_kernel(const float* __restrict__ part, const float* __res
 
 struct PostArgs {
     const float* cam;      // member e, window b: cam + e*cam_estride + b*L
-    const float* logits;   // logits + e*lg_estride + 2*b
-    const float* cmax;     // cmax + e*cmax_estride + b   (unused when OWN_MAX)
-    size_t cam_estride, lg_estride, cmax_estride;
+    const float* logits;   // logits + e*lg_estride + 2*b                 (OWN_MAX only)
+    const double* hdr;     // [B][E + 1] window headers from header_kernel  (!OWN_MAX)
+    size_t cam_estride, lg_estride;
     const float* x;        // [B][L]
     const double* x64;     // [B][L] or null
-    const int8_t* y;       // [B] or null
-    double* prob_out;      // [B]
+    const int8_t* y;       // [B] or null                                  (OWN_MAX only)
+    double* prob_out;      // [B]                                          (OWN_MAX only)
     float* avg_out;        // [B][L] or null
     float* state_out;      // [B][L]
     float* power_out;      // [B][L] or null
     int E, B, L, w_ma, gate_mode, pred_f64;
     double p_on, scale_mul, scale_add;
 };
+
+// Window headers for post_kernel, one thread per window (camal_localize: replaces one logits launch per
+// member and pass, and the softmax / vote every post_kernel tile used to redo):
+//   logits[e][b][k] = sum over head tiles of part / L + b_fc      (camal_resnet.py:23)
+//   p1 = softmax(logits)[1] in float32, label = p1 > p0           (class_activation_map.py:59-64)
+//   prob = sum_e p1 / E in float64; gates (core.py:292-300); vote = round_half_even(prob)   (core.py:305,320-324)
+//   hdr[b] = { vote (0: the window's prediction is 0), per member 1/max(clip(cam)) or 0 if it adds nothing }
+struct HeaderArgs {
+    const float* part;      // member e, window b: part + e*part_estride + b*ntiles[e]*2
+    const float* cmax;      // cmax + e*cmax_estride + b
+    float* logits;          // out: logits + e*lg_estride + 2*b
+    size_t part_estride, cmax_estride, lg_estride;
+    const float* bfc[CAMAL_MAX_MEMBERS];  // each member's head bias [2]
+    int ntiles[CAMAL_MAX_MEMBERS];
+    const int8_t* y;        // [B] or null
+    double* prob_out;       // [B]
+    double* hdr;            // [B][E + 1]
+    int E, B, L, gate_mode;
+};
+
+__global__ __launch_bounds__(128) void header_kernel(HeaderArgs a) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    double rinv[CAMAL_MAX_MEMBERS];
+    double psum = 0.0;
+    int lab0 = 0;
+    for (int e = 0; e < a.E; ++e) {
+        float l0, l1;
+        member_logits(a.part + e * a.part_estride + (size_t)b * a.ntiles[e] * 2, a.ntiles[e], a.L, a.bfc[e], l0, l1);
+        float* lg = a.logits + e * a.lg_estride + 2 * (size_t)b;
+        lg[0] = l0;
+        lg[1] = l1;
+        const float m = fmaxf(l0, l1);
+        const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+        const float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
+        const int lab = p1 > p0 ? 1 : 0;
+        if (e == 0) lab0 = lab;
+        psum += (double)p1;
+        const float cm = a.cmax[e * a.cmax_estride + b];
+        rinv[e] = (lab && cm > 0.f) ? 1.0 / (double)cm : 0.0;
+    }
+    bool skip = false;
+    if (a.y) skip = a.y[b] < 1;
+    else if (a.gate_mode == 1) skip = lab0 < 1;
+    const double prob = skip ? 0.0 : psum / (double)a.E;
+    const double vote = rint(prob);  // np.round: half to even
+    const bool pass = !skip && vote != 0.0;
+    a.prob_out[b] = prob;
+    double* h = a.hdr + (size_t)b * (a.E + 1);
+    h[0] = pass ? vote : 0.0;
+    for (int e = 0; e < a.E; ++e) h[1 + e] = pass ? rinv[e] : 0.0;
+}
 
 // np.round(2/(1+exp(-z)) - 1) with z = (sum/w)*x  (core.py:431-437), values -1, -0, +0, 1.
 // The rounded value only depends on which side of +-ln 3 (and of 0) z falls, so the exponential
@@ -1260,13 +1312,28 @@ __device__ __forceinline__ double attention_state(double sum, int w, double inv_
     return rint(2.0 * (1.0 / (1.0 + exp(-z))) - 1.0);
 }
 
+// NS values of one window row starting at byte offset off0 (VEC: NS consecutive floats in one 16-byte load,
+// the row is then 16-byte aligned) or at the NS byte offsets off[] (one dword each)
+template <int NS, bool VEC>
+__device__ __forceinline__ void load_row(const float* rowp, const unsigned (&off)[NS], float (&v)[NS]) {
+    const char* c = reinterpret_cast<const char*>(rowp);
+    if constexpr (VEC) {
+        static_assert(NS == 4, "one float4 per lane");
+        const float4 t = *reinterpret_cast<const float4*>(c + off[0]);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) v[j] = *reinterpret_cast<const float*>(c + off[j]);
+    }
+}
+
 // pred[t] of core.py:308-324 at NS positions of window row `row`: members that voted 'on' add
 // clip(cam)/max(clip(cam)) in member order (float32 sum when the caller's data was float32,
 // float64 otherwise), /E, * vote.  c/max as float32(float64(c) * (1/float64(max))): 53 bits
 // cover the correctly rounded float32 quotient of two float32 numbers.
-template <int NS, bool F64, int MU>
-__device__ __forceinline__ void ensemble_pred(const PostArgs& a, const float* s_max, const double* s_rinv,
-                                              const int* s_lab, size_t row, const unsigned (&off)[NS],
+// rinv[e] = 1/max of member e, or 0 when the member adds nothing (voted off, max 0, window off): wave-uniform.
+template <int NS, bool F64, int MU, bool VEC>
+__device__ __forceinline__ void ensemble_pred(const PostArgs& a, const double* rinv, size_t row, const unsigned (&off)[NS],
                                               const bool (&ok)[NS], double vote, double (&out)[NS]) {
     // off[j]: BYTE offset of the position inside the window row, already clamped into it (a position that
     // is not wanted still loads a valid address; ok[j] = false zeroes its result).  32-bit byte offsets on a
@@ -1284,16 +1351,10 @@ __device__ __forceinline__ void ensemble_pred(const PostArgs& a, const float* s_
 #pragma unroll
         for (int u = 0; u < MU; ++u) {
             const int e = e0 + u < a.E ? e0 + u : 0;
-            const bool on = __builtin_amdgcn_readfirstlane((int)(e0 + u < a.E && s_lab[e] && s_max[e] > 0.f));
-            ri[u] = 0.0;
+            ri[u] = e0 + u < a.E ? rinv[e] : 0.0;
 #pragma unroll
             for (int j = 0; j < NS; ++j) v[u][j] = 0.f;
-            if (on) {  // wave-uniform
-                ri[u] = s_rinv[e];
-                const char* c = reinterpret_cast<const char*>(a.cam + e * a.cam_estride + row);
-#pragma unroll
-                for (int j = 0; j < NS; ++j) v[u][j] = *reinterpret_cast<const float*>(c + off[j]);
-            }
+            if (ri[u] != 0.0) load_row<NS, VEC>(a.cam + e * a.cam_estride + row, off, v[u]);  // wave-uniform branch
         }
 #pragma unroll
         for (int u = 0; u < MU; ++u) {
@@ -1315,12 +1376,18 @@ __device__ __forceinline__ void ensemble_pred(const PostArgs& a, const float* s_
     }
 }
 
-template <bool OWN_MAX, int MU>
+// OWN_MAX = false (camal_localize): the window's header comes from header_kernel through wave-uniform (scalar)
+//   loads, the row maxima from the CAM-head epilogue: the CAM rows are read exactly once, and nothing sits
+//   between the kernel's start and its loads.
+// OWN_MAX = true (camal_postprocess on rows and logits the caller brought): softmax, vote and a scan of the
+//   window's rows for their maxima in the kernel.
+// VEC: L % 4 == 0, every lane works on 4 consecutive timesteps through 16-byte loads and stores; else lane t of
+//   the tile takes timesteps t, t + 256, ... through dwords.
+template <bool OWN_MAX, int MU, bool VEC>
 __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
-    __shared__ float s_max[CAMAL_MAX_MEMBERS];
-    __shared__ double s_rinv[CAMAL_MAX_MEMBERS];
-    __shared__ float s_p1[CAMAL_MAX_MEMBERS];
-    __shared__ int s_lab[CAMAL_MAX_MEMBERS];
+    __shared__ double s_rinv[OWN_MAX ? CAMAL_MAX_MEMBERS : 1];
+    __shared__ float s_p1[OWN_MAX ? CAMAL_MAX_MEMBERS : 1];
+    __shared__ int s_lab[OWN_MAX ? CAMAL_MAX_MEMBERS : 1];
     __shared__ float s_red[4];
     __shared__ int s_y;
     __shared__ double s_pred[POST_TILE + 64];
@@ -1329,41 +1396,77 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
     const int n = min(POST_TILE, L - c0);
     const size_t row = (size_t)b * L;
 
-    // window header, one lane per member: float32 softmax, label, row maximum.  Its loads (small, still
-    // in L2 from the kernels that wrote them) are issued FIRST and unconditionally; the loads of the
-    // aggregate (HBM; needed whatever the vote) follow, so the header only waits for its own data.
-    // Raw loads only up here: a conversion or a branch in between makes the loads wait in turn.
-    const int he = min(tid, E - 1);
-    const float* lg = a.logits + he * a.lg_estride + 2 * (size_t)b;
-    const float l0 = lg[0], l1 = lg[1];
-    const float cm = OWN_MAX ? 0.f : a.cmax[he * a.cmax_estride + b];
-    const int yv = *(a.y ? a.y + b : reinterpret_cast<const int8_t*>(lg));  // always a valid address
-    __builtin_amdgcn_sched_barrier(0);  // keep the header loads ahead of the aggregate's in the queue
-    float xf[POST_PER_LANE];
+    // positions of this lane inside the tile, and their (clamped) byte offsets inside the window row
+    int pos[POST_PER_LANE];
+    unsigned off[POST_PER_LANE];
+    bool ok[POST_PER_LANE];
 #pragma unroll
-    for (int j = 0; j < POST_PER_LANE; ++j) xf[j] = (a.x + row)[(unsigned)(c0 + min(tid + 256 * j, n - 1))];
-    __builtin_amdgcn_sched_barrier(0);
-    if (tid < E) {
-        const float m = fmaxf(l0, l1);
-        const float e0 = expf(l0 - m), e1 = expf(l1 - m);
-        const float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
-        s_p1[tid] = p1;
-        s_lab[tid] = p1 > p0 ? 1 : 0;
-        s_max[tid] = cm;
-        s_rinv[tid] = cm > 0.f ? 1.0 / (double)cm : 0.0;
-        if (tid == 0) s_y = yv;
+    for (int j = 0; j < POST_PER_LANE; ++j) {
+        pos[j] = VEC ? 4 * tid + j : tid + 256 * j;
+        ok[j] = pos[j] < n;
+        // VEC: n is a multiple of 4, a lane is in or out as a whole; an idle lane re-reads the tile's first chunk
+        off[j] = 4u * (unsigned)(c0 + (VEC ? (ok[0] ? pos[j] : j) : min(pos[j], n - 1)));
     }
-    __syncthreads();
-    // every lane repeats the (ordered, float64) member sum: broadcast LDS reads, no second barrier
-    bool skip = false;
-    if (a.y) skip = s_y < 1;
-    else if (a.gate_mode == 1) skip = s_lab[0] < 1;
-    double psum = 0.0;
-    for (int e = 0; e < E; ++e) psum += (double)s_p1[e];
-    const double prob = skip ? 0.0 : psum / (double)E;
-    const double vote = rint(prob);  // np.round: half to even
-    if (tid == 0 && blockIdx.x == 0) a.prob_out[b] = prob;
-    const bool pass = !skip && vote != 0.0;  // else pred == 0 on the whole window
+
+    double vote;
+    bool pass;
+    const double* rinv;
+    float xf[POST_PER_LANE];
+    if constexpr (!OWN_MAX) {
+        const double* h = a.hdr + (size_t)b * (E + 1);  // wave-uniform address
+        vote = h[0];
+        pass = vote != 0.0;
+        rinv = h + 1;
+        load_row<POST_PER_LANE, VEC>(a.x + row, off, xf);
+    } else {
+        // window header, one lane per member: float32 softmax, label.  Its loads are issued FIRST and
+        // unconditionally; the loads of the aggregate (needed whatever the vote) follow.
+        const int he = min(tid, E - 1);
+        const float* lg = a.logits + he * a.lg_estride + 2 * (size_t)b;
+        const float l0 = lg[0], l1 = lg[1];
+        const int yv = *(a.y ? a.y + b : reinterpret_cast<const int8_t*>(lg));  // always a valid address
+        __builtin_amdgcn_sched_barrier(0);
+        load_row<POST_PER_LANE, VEC>(a.x + row, off, xf);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tid < E) {
+            const float m = fmaxf(l0, l1);
+            const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+            const float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
+            s_p1[tid] = p1;
+            s_lab[tid] = p1 > p0 ? 1 : 0;
+            if (tid == 0) s_y = yv;
+        }
+        __syncthreads();
+        bool skip = false;
+        if (a.y) skip = s_y < 1;
+        else if (a.gate_mode == 1) skip = s_lab[0] < 1;
+        double psum = 0.0;
+        for (int e = 0; e < E; ++e) psum += (double)s_p1[e];
+        const double prob = skip ? 0.0 : psum / (double)E;
+        vote = rint(prob);  // np.round: half to even
+        if (tid == 0 && blockIdx.x == 0) a.prob_out[b] = prob;
+        pass = !skip && vote != 0.0;
+        rinv = s_rinv;
+        // the rows' maxima (core.py:311): scan the window's rows of the members that voted on
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int e = 0; e < E; ++e) {
+            float m = 0.f;
+            if (pass && s_lab[e]) {
+                const float* c = a.cam + e * a.cam_estride + row;
+                for (int t = tid; t < L; t += 256) m = fmaxf(m, clip_cam(c[t]));
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            }
+            __syncthreads();
+            if (lane == 0) s_red[wave] = m;
+            __syncthreads();
+            if (tid == 0) {
+                const float mm = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+                s_rinv[e] = mm > 0.f ? 1.0 / (double)mm : 0.0;
+            }
+        }
+        __syncthreads();
+    }
 
     const int w = a.w_ma, hi = (w - 1) / 2, lo = hi - w + 1;  // lo <= 0
     const double inv_w = 1.0 / (double)w;
@@ -1371,84 +1474,68 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
     double xd[POST_PER_LANE];
     if (a.x64) {
 #pragma unroll
-        for (int j = 0; j < POST_PER_LANE; ++j) xd[j] = (a.x64 + row)[(unsigned)(c0 + min(tid + 256 * j, n - 1))];
+        for (int j = 0; j < POST_PER_LANE; ++j) xd[j] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.x64 + row) + 2 * (size_t)off[j]);
     }
 
     if (pass) {
-        if (OWN_MAX) {
-            const int lane = tid & 63, wave = tid >> 6;
-            for (int e = 0; e < E; ++e) {
-                float m = 0.f;
-                if (s_lab[e]) {
-                    const float* c = a.cam + e * a.cam_estride + row;
-                    for (int t = tid; t < L; t += 256) m = fmaxf(m, clip_cam(c[t]));
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-                }
-                __syncthreads();
-                if (lane == 0) s_red[wave] = m;
-                __syncthreads();
-                if (tid == 0) {
-                    const float mm = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-                    s_max[e] = mm;
-                    s_rinv[e] = mm > 0.f ? 1.0 / (double)mm : 0.0;
-                }
-            }
-            __syncthreads();
-        }
-
         // ---- ensemble-averaged, vote-gated CAM of the tile -> LDS slot (position - c0 - lo)
         // np.convolve(p, ones(w), 'same')[t] = sum_{m = t + lo .. t + hi} p[m]: the tile needs pred on
         // [c0 + lo, c0 + n + hi)
         {
-            unsigned off[POST_PER_LANE];
-            bool ok[POST_PER_LANE];
             double pr[POST_PER_LANE];
+            if (a.pred_f64) ensemble_pred<POST_PER_LANE, true, MU, VEC>(a, rinv, row, off, ok, vote, pr);
+            else ensemble_pred<POST_PER_LANE, false, MU, VEC>(a, rinv, row, off, ok, vote, pr);
 #pragma unroll
-            for (int j = 0; j < POST_PER_LANE; ++j) {
-                const int i = tid + 256 * j;
-                off[j] = 4u * (unsigned)(c0 + min(i, n - 1));
-                ok[j] = i < n;
-            }
-            if (a.pred_f64) ensemble_pred<POST_PER_LANE, true, MU>(a, s_max, s_rinv, s_lab, row, off, ok, vote, pr);
-            else ensemble_pred<POST_PER_LANE, false, MU>(a, s_max, s_rinv, s_lab, row, off, ok, vote, pr);
-#pragma unroll
-            for (int j = 0; j < POST_PER_LANE; ++j) {
-                const int i = tid + 256 * j;
-                if (i < n) s_pred[i - lo] = pr[j];
-            }
+            for (int j = 0; j < POST_PER_LANE; ++j)
+                if (ok[j]) s_pred[pos[j] - lo] = pr[j];
         }
         if (tid < w - 1) {  // halo: -lo positions before the tile, hi after it (zero outside the window)
             const bool left = tid < -lo;
             const int t = left ? c0 + lo + tid : c0 + n + (tid + lo);
-            unsigned off[1] = {4u * (unsigned)min(max(t, 0), L - 1)};
-            bool ok[1] = {t >= 0 && t < L};
+            unsigned hoff[1] = {4u * (unsigned)min(max(t, 0), L - 1)};
+            bool hok[1] = {t >= 0 && t < L};
             double pr[1];
-            if (a.pred_f64) ensemble_pred<1, true, MU>(a, s_max, s_rinv, s_lab, row, off, ok, vote, pr);
-            else ensemble_pred<1, false, MU>(a, s_max, s_rinv, s_lab, row, off, ok, vote, pr);
+            if (a.pred_f64) ensemble_pred<1, true, MU, false>(a, rinv, row, hoff, hok, vote, pr);
+            else ensemble_pred<1, false, MU, false>(a, rinv, row, hoff, hok, vote, pr);
             s_pred[left ? tid : n + tid] = pr[0];
         }
         __syncthreads();
     }
 
     // ---- moving average, rectified sigmoid of (ma * aggregate), round, power
+    float st4[POST_PER_LANE], av4[POST_PER_LANE], pw4[POST_PER_LANE];
 #pragma unroll
     for (int j = 0; j < POST_PER_LANE; ++j) {
-        const int i = tid + 256 * j;
-        if (i >= n) continue;
-        const unsigned o = (unsigned)(c0 + i);
+        st4[j] = av4[j] = pw4[j] = 0.f;
+        if (!ok[j]) continue;
+        const int i = pos[j];
         double sum = 0.0;
         if (pass)
             for (int m = 0; m < w; ++m) sum += s_pred[i + m];
         const double xv = a.x64 ? xd[j] : (double)xf[j];
         const double st = attention_state(sum, w, inv_w, xv);
-        (a.state_out + row)[o] = (float)st;
-        if (a.avg_out) (a.avg_out + row)[o] = pass ? (float)s_pred[i - lo] : 0.f;
-        if (a.power_out) {
-            const double agg = xv * a.scale_mul + a.scale_add;
-            double yh = (double)(int)st * a.p_on;  // astype(int) of -1, -0, 0, 1
-            if (yh > agg) yh = agg;
-            (a.power_out + row)[o] = (float)yh;
+        st4[j] = (float)st;
+        av4[j] = pass ? (float)s_pred[i - lo] : 0.f;
+        const double agg = xv * a.scale_mul + a.scale_add;
+        double yh = (double)(int)st * a.p_on;  // astype(int) of -1, -0, 0, 1
+        if (yh > agg) yh = agg;
+        pw4[j] = (float)yh;
+    }
+    if constexpr (VEC) {
+        if (ok[0]) {
+            const size_t o = row + c0 + pos[0];
+            *reinterpret_cast<float4*>(a.state_out + o) = make_float4(st4[0], st4[1], st4[2], st4[3]);
+            if (a.avg_out) *reinterpret_cast<float4*>(a.avg_out + o) = make_float4(av4[0], av4[1], av4[2], av4[3]);
+            if (a.power_out) *reinterpret_cast<float4*>(a.power_out + o) = make_float4(pw4[0], pw4[1], pw4[2], pw4[3]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < POST_PER_LANE; ++j) {
+            if (!ok[j]) continue;
+            const size_t o = row + c0 + pos[j];
+            a.state_out[o] = st4[j];
+            if (a.avg_out) a.avg_out[o] = av4[j];
+            if (a.power_out) a.power_out[o] = pw4[j];
         }
     }
 }
