@@ -706,6 +706,53 @@ int camal_attention(const double* soft, const double* x, int B, int L, int w_ma,
     return 0;
 }
 
+static int win_scan_blocks(int n_wins) { return (n_wins + WIN_SCAN_BLOCK - 1) / WIN_SCAN_BLOCK; }
+
+size_t camal_windows_workspace_bytes(int n_wins) {
+    if (n_wins < 1) return 0;
+    return align_up((size_t)n_wins) + align_up((size_t)n_wins * 4) + align_up((size_t)win_scan_blocks(n_wins) * 4);
+}
+
+int camal_windows_count(long long T, int W, int stride) {
+    if (T < W || W < 1 || stride < 1) return 0;
+    const long long n = W == stride ? T / stride : 1 + (T - W) / stride;  // data_processing.py:377-380
+    return n > 0x7fffffffLL ? 0x7fffffff : (int)n;
+}
+
+int camal_build_windows(const void* series, int series_is_f64, int n_rows, long long T, int W, int stride, int app,
+                        double stat1, double stat2, float* x_out, double* x64_out, int8_t* label_out, float* app_power_out,
+                        int8_t* app_state_out, int* index_out, int* count_out, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+    if (!series || !x_out || !count_out || !workspace) return fail(CAMAL_ERR_ARG, "series_dev, x_out, count_out and workspace_dev are required");
+    if (n_rows < 1 || T < 1 || W < 1 || stride < 1) return fail(CAMAL_ERR_ARG, "n_rows, T, W and stride must be >= 1");
+    if (app < 1) return fail(CAMAL_ERR_ARG, "app is the 1-based appliance index");
+    if ((label_out || app_power_out || app_state_out) && 2 * app >= n_rows)
+        return fail(CAMAL_ERR_ARG, "the series has no (power, status) rows for that appliance");
+    if (stat2 == 0.0) return fail(CAMAL_ERR_ARG, "stat2 must not be 0");
+    const int n_wins = camal_windows_count(T, W, stride);
+    if (n_wins < 1) return fail(CAMAL_ERR_ARG, "the series is shorter than one window");
+    if (workspace_bytes < camal_windows_workspace_bytes(n_wins)) return fail(CAMAL_ERR_ARG, "workspace smaller than camal_windows_workspace_bytes(n_wins)");
+    WinArgs a;
+    a.s32 = series_is_f64 ? nullptr : (const float*)series;
+    a.s64 = series_is_f64 ? (const double*)series : nullptr;
+    a.T = T; a.n_rows = n_rows; a.W = W; a.stride = stride; a.n_wins = n_wins; a.app = app;
+    a.stat1 = stat1; a.stat2 = stat2;
+    char* ws = (char*)workspace;
+    a.keep = (unsigned char*)ws; ws += align_up((size_t)n_wins);
+    a.pos = (int*)ws; ws += align_up((size_t)n_wins * 4);
+    a.blocksum = (int*)ws;
+    a.x_out = x_out; a.x64_out = x64_out; a.label_out = label_out; a.app_power_out = app_power_out;
+    a.app_state_out = app_state_out; a.index_out = index_out; a.count_out = count_out;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = win_scan_blocks(n_wins);
+    hipLaunchKernelGGL(win_flag_kernel, dim3(n_wins), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(win_scan_block_kernel, dim3(nb), dim3(WIN_SCAN_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(win_scan_top_kernel, dim3(1), dim3(WIN_SCAN_BLOCK), 0, s, a, nb);
+    hipLaunchKernelGGL(win_copy_kernel, dim3(n_wins), dim3(256), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 static int nilm_blocks(size_t n) {
     const size_t want = (n + (size_t)NILM_THREADS * 8 - 1) / ((size_t)NILM_THREADS * 8);
     return (int)std::max<size_t>(1, std::min<size_t>(want, NILM_MAX_BLOCKS));

@@ -1344,7 +1344,7 @@ __device__ __forceinline__ void ensemble_pred(const PostArgs& a, const double* r
     for (int j = 0; j < NS; ++j) { accf[j] = 0.f; accd[j] = 0.0; }
     // MU members per round: all their loads are in flight before the first is consumed (every round is
     // one more memory round trip on the workgroup's critical path; the host picks MU);
-    // a member that is off loads nothing and adds an exact +0
+    // a member that is off adds an exact +0 (clip_cam leaves a finite value, times ri = 0)
     for (int e0 = 0; e0 < a.E; e0 += MU) {
         float v[MU][NS];
         double ri[MU];
@@ -1352,13 +1352,13 @@ __device__ __forceinline__ void ensemble_pred(const PostArgs& a, const double* r
         for (int u = 0; u < MU; ++u) {
             const int e = e0 + u < a.E ? e0 + u : 0;
             ri[u] = e0 + u < a.E ? rinv[e] : 0.0;
-#pragma unroll
-            for (int j = 0; j < NS; ++j) v[u][j] = 0.f;
-            if (ri[u] != 0.0) load_row<NS, VEC>(a.cam + e * a.cam_estride + row, off, v[u]);  // wave-uniform branch
+            // no branch around the load (a branch makes the round's loads wait for each other): a member that
+            // is off reads the aggregate's row instead, which this workgroup has just pulled into the caches,
+            // and its values meet ri = 0 below
+            load_row<NS, VEC>(ri[u] != 0.0 ? a.cam + e * a.cam_estride + row : a.x + row, off, v[u]);
         }
 #pragma unroll
         for (int u = 0; u < MU; ++u) {
-            if (ri[u] == 0.0) continue;  // wave-uniform: member off
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
                 const float q = (float)((double)clip_cam(v[u][j]) * ri[u]);
@@ -1553,6 +1553,117 @@ __global__ __launch_bounds__(256) void attention_kernel(const double* __restrict
     for (int m = t + lo; m <= t + hi; ++m)
         if (m >= 0 && m < L) sum += sb[m];
     out[(size_t)b * L + t] = attention_state(sum, w, 1.0 / (double)w, x[(size_t)b * L + t]);
+}
+
+// ---------------------------------------------------------------------------------------
+// Window builder + scaler + weak labels in front of camal_localize: the window loop of
+// *_DataBuilder.get_nilm_dataset (src/helpers/data_processing.py:377-400), NILMscaler.transform on the
+// aggregate channel (src/helpers/torch_dataset.py:105-111) and nilmdataset_to_clfdataset (:17-33).
+//   series [n_rows][T]: row 0 aggregate power, then (power, status) per appliance
+//   window i = columns i*stride .. i*stride + W - 1; a window with a NaN in ANY row is dropped (:388),
+//   survivors keep their order: flags -> exclusive scan (two levels, fixed order) -> copy.
+// HBM-bound: the series is read twice (flag pass, copy pass), the outputs written once.
+// ---------------------------------------------------------------------------------------
+#define WIN_SCAN_BLOCK 1024
+
+struct WinArgs {
+    const float* s32;      // one of s32 / s64
+    const double* s64;
+    long long T;
+    int n_rows, W, stride, n_wins, app;   // app: appliance (1-based) whose status row gives the weak label
+    double stat1, stat2;                  // x_scaled = (agg - stat1) / stat2 in float64
+    unsigned char* keep;   // [n_wins]   1: no NaN
+    int* pos;              // [n_wins]   exclusive scan of keep (after win_scan_*)
+    int* blocksum;         // [ceil(n_wins / WIN_SCAN_BLOCK)]
+    float* x_out; double* x64_out; int8_t* label_out; float* app_power_out; int8_t* app_state_out;
+    int* index_out; int* count_out;
+};
+
+__device__ __forceinline__ double win_at(const WinArgs& a, int row, long long t) {
+    return a.s64 ? a.s64[(size_t)row * a.T + t] : (double)a.s32[(size_t)row * a.T + t];
+}
+
+__global__ __launch_bounds__(256) void win_flag_kernel(WinArgs a) {
+    const int i = blockIdx.x;
+    const long long t0 = (long long)i * a.stride;
+    int bad = 0;
+    for (int r = 0; r < a.n_rows; ++r)
+        for (int t = threadIdx.x; t < a.W; t += 256) {
+            const double v = win_at(a, r, t0 + t);
+            bad |= (v != v);
+        }
+    bad = __syncthreads_or(bad);
+    if (threadIdx.x == 0) a.keep[i] = bad ? 0 : 1;
+}
+
+// exclusive scan of keep[] inside blocks of WIN_SCAN_BLOCK windows (one thread per window) + the block totals
+__global__ __launch_bounds__(WIN_SCAN_BLOCK) void win_scan_block_kernel(WinArgs a) {
+    __shared__ int sh[WIN_SCAN_BLOCK];
+    const int i = blockIdx.x * WIN_SCAN_BLOCK + threadIdx.x;
+    const int v = i < a.n_wins ? a.keep[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < WIN_SCAN_BLOCK; o <<= 1) {  // Hillis-Steele, inclusive
+        const int add = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += add;
+        __syncthreads();
+    }
+    if (i < a.n_wins) a.pos[i] = sh[threadIdx.x] - v;
+    if (threadIdx.x == WIN_SCAN_BLOCK - 1) a.blocksum[blockIdx.x] = sh[threadIdx.x];
+}
+
+// exclusive scan of the block totals by ONE block (chunks of 1024 with a running carry) + the survivor count
+__global__ __launch_bounds__(WIN_SCAN_BLOCK) void win_scan_top_kernel(WinArgs a, int nblocks) {
+    __shared__ int sh[WIN_SCAN_BLOCK];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nblocks; base += WIN_SCAN_BLOCK) {
+        const int i = base + threadIdx.x;
+        const int v = i < nblocks ? a.blocksum[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < WIN_SCAN_BLOCK; o <<= 1) {
+            const int add = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const int c = carry;
+        if (i < nblocks) a.blocksum[i] = c + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == WIN_SCAN_BLOCK - 1) carry = c + sh[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *a.count_out = carry;
+}
+
+__global__ __launch_bounds__(256) void win_copy_kernel(WinArgs a) {
+    const int i = blockIdx.x;
+    if (!a.keep[i]) return;
+    const int dst = a.blocksum[i / WIN_SCAN_BLOCK] + a.pos[i];
+    const long long t0 = (long long)i * a.stride;
+    const size_t o = (size_t)dst * a.W;
+    const int prow = 2 * a.app - 1, srow = 2 * a.app;  // rows of the appliance's power and status
+    const bool has_app = srow < a.n_rows;
+    int any = 0;
+    for (int t = threadIdx.x; t < a.W; t += 256) {
+        const double xs = (win_at(a, 0, t0 + t) - a.stat1) / a.stat2;
+        a.x_out[o + t] = (float)xs;
+        if (a.x64_out) a.x64_out[o + t] = xs;
+        if (has_app) {
+            const double st = win_at(a, srow, t0 + t);
+            any |= (st != 0.0);  // data[i, 1, 1, :].any()
+            if (a.app_power_out) a.app_power_out[o + t] = (float)win_at(a, prow, t0 + t);
+            if (a.app_state_out) a.app_state_out[o + t] = (int8_t)(int)st;
+        }
+    }
+    any = __syncthreads_or(any);
+    if (threadIdx.x == 0) {
+        if (a.label_out) a.label_out[dst] = any ? 1 : 0;
+        if (a.index_out) a.index_out[dst] = i;
+    }
 }
 
 // ---------------------------------------------------------------------------------------

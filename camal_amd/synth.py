@@ -73,3 +73,25 @@ def metric_arrays(seed, n=4000):
     y_clf = (rng.random(m) < 0.4).astype(np.int64)
     score = np.round(np.clip(0.5 + 0.35 * (2 * y_clf - 1) * rng.random(m) + 0.2 * rng.normal(size=m), 0, 1), 2)
     return y, y_hat, y_state, y_hat_state, y_clf, score
+
+
+def house_series(T=20000, seed=0, n_app=1, dtype=np.float64, nan_runs=6):
+    """A long series as ``_get_stems`` lays it out (data_processing.py:366-367): row 0 aggregate power in W, then
+    (power, status) per appliance, with a few runs of NaN (meter gaps) that the window loop must drop."""
+    rng = np.random.default_rng(seed)
+    rows = np.zeros((1 + 2 * n_app, T))
+    rows[0] = np.abs(rng.normal(150.0, 50.0, T))
+    for a in range(n_app):
+        p = np.zeros(T)
+        for _ in range(max(1, T // 1500)):
+            start = int(rng.integers(0, T - 50))
+            dur = int(rng.integers(3, 40))
+            p[start:start + dur] = rng.uniform(800.0, 2500.0)
+        rows[1 + 2 * a] = p
+        rows[2 + 2 * a] = (p > 0).astype(float)
+        rows[0] += p
+    for _ in range(nan_runs):
+        start = int(rng.integers(0, T - 30))
+        r = int(rng.integers(0, 1 + 2 * n_app))
+        rows[r, start:start + int(rng.integers(1, 25))] = np.nan
+    return rows.astype(dtype)

@@ -141,6 +141,30 @@ int camal_nilm_sums(const float* y32_dev, const double* y64_dev, const float* yh
                     const float* yhat_state_dev, size_t n, double* sums_out, void* workspace_dev,
                     size_t workspace_bytes, void* stream);
 
+/* Window builder + scaler + weak labels in front of camal_localize, on the device (the data that feeds the hot
+ * path never takes the pandas / NumPy detour): replaces the window loop of *_DataBuilder.get_nilm_dataset
+ * (src/helpers/data_processing.py:377-400), NILMscaler.transform on the aggregate channel
+ * (src/helpers/torch_dataset.py:105-111) and nilmdataset_to_clfdataset (data_processing.py:17-33).
+ *   series_dev [n_rows][T]  float64 (series_is_f64 = 1) or float32 rows: row 0 aggregate power, then (power,
+ *                           status) per appliance, as _get_stems lays them out.
+ *   windows i = 0 .. camal_windows_count(T, W, stride) - 1 start at i * stride; a window with a NaN in ANY row
+ *   is dropped (:388); the survivors keep their order.  Outputs are sized for all windows, the first
+ *   *count_out (device int) rows are written:
+ *   x_out [n][W]        float32((aggregate - stat1) / stat2), the division in float64 as NILMscaler does it
+ *                       ('MinMax': pass stat2 = max - min); this is what CamALResNet is fed (.float());
+ *   x64_out [n][W]      the same in float64 (what predict's attention module multiplies by), or NULL;
+ *   label_out [n]       int8 weak label: any(status of appliance `app` != 0) (data_processing.py:28), or NULL;
+ *   app_power_out, app_state_out [n][W]  float32 power / int8 status rows of appliance `app` (the y and
+ *                       y_state of CamAL.test's metrics), or NULL;
+ *   index_out [n]       int32 index i of each surviving window, or NULL.
+ *   workspace_dev       camal_windows_workspace_bytes(n_wins) bytes; the library allocates nothing.         */
+int camal_windows_count(long long T, int W, int stride);
+size_t camal_windows_workspace_bytes(int n_wins);
+int camal_build_windows(const void* series_dev, int series_is_f64, int n_rows, long long T, int W, int stride, int app,
+                        double stat1, double stat2, float* x_out, double* x64_out, int8_t* label_out,
+                        float* app_power_out, int8_t* app_state_out, int* index_out, int* count_out,
+                        void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* ------------------------------- training (one ResNet member) -------------------------------
  * Replaces the per-batch body of BasedClassifTrainer.__train (torch_trainer.py:281-298) for
  * CamALResNet in train() mode: forward with BatchNorm batch statistics (biased variance,

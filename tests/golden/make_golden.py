@@ -219,9 +219,39 @@ def metrics_case(name="metrics_ref"):
     print(f"{name}: loc[0]={loc[0].tolist()} clf[0]={clf[0].tolist()}")
 
 
+def windows_case(name="windows_ref"):
+    """The reference's own NILMscaler (torch_dataset.py:22-156) and nilmdataset_to_clfdataset
+    (data_processing.py:17-33) on 4-D arrays that oracle/windows_oracle.py builds from seeded series (the
+    builders' window loop itself needs the datasets' files and cannot run here)."""
+    from oracle import windows_oracle
+    from src.helpers.data_processing import nilmdataset_to_clfdataset
+    from src.helpers.torch_dataset import NILMscaler
+    cases = [(401, 510, 510, 1000), (402, 128, 64, "StandardScaling"), (403, 96, 96, "MaxScaling"), (404, 200, 50, "MeanMaxScaling")]
+    out = dict(seeds=np.array([c[0] for c in cases]), W=np.array([c[1] for c in cases]), S=np.array([c[2] for c in cases]),
+               kinds=np.array([str(c[3]) for c in cases]))
+    for seed, W, S, kind in cases:
+        stems = synth.house_series(6000, seed=seed)
+        X, kept = windows_oracle.nilm_dataset(stems, W, S)
+        sc = NILMscaler(power_scaling_type=kind, appliance_scaling_type="SameAsPower")  # None fails the reference's own assert (:38)
+        Xs = sc.fit_transform(X.copy())
+        Xa, y = nilmdataset_to_clfdataset(Xs)
+        out[f"stat_{seed}"] = np.array([float(sc.power_stat1), float(sc.power_stat2)])
+        out[f"kept_{seed}"] = kept
+        out[f"y_{seed}"] = np.asarray(y, np.int8)
+        out[f"x_{seed}"] = np.asarray(Xa[::3], np.float64)  # every third window, float64 as the reference holds it
+        out[f"app_{seed}"] = np.asarray(Xs[::7, 1, 0, ::5], np.float64)  # scaled appliance channel, sampled
+        back = sc.inverse_transform(Xs)
+        out[f"inv_err_{seed}"] = np.array(float(np.abs(back[:, 0, 0, :] - X[:, 0, 0, :]).max()))
+        print(f"{name}: seed={seed} W={W} S={S} {kind}: {len(X)} windows kept, labels on {float(np.mean(y)):.2f}")
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "metrics":
         return metrics_case()
+    if len(sys.argv) > 1 and sys.argv[1] == "windows":
+        return windows_case()
+    windows_case()
     metrics_case()
     train_case("train_k7_l96", k=7, seed=201, n=48, length=96, batch=16, epochs=2)
     train_case("train_k25_l70", k=25, seed=202, n=24, length=70, batch=12, epochs=1)

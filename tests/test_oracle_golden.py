@@ -99,3 +99,30 @@ def test_torch_path_matches_reference(name):
     states, prob = torch_path.predict_loop(case_state_dicts(c), c["data"], w_ma=int(c["w_ma"]))
     assert np.abs(prob - c["prob_detect"]).max() < 1e-6
     assert (states == c["states"]).mean() >= 0.999
+
+
+def test_window_oracle_and_scaler_mirror_match_the_reference_fixture():
+    """tests/golden/windows_ref.npz: the reference's NILMscaler.fit_transform / nilmdataset_to_clfdataset outputs
+    on the 4-D arrays oracle/windows_oracle.py builds (make_golden.py::windows_case)."""
+    from camal_amd import synth
+    from camal_amd.windows import NILMscaler, n_windows
+    from oracle import windows_oracle
+    from tests.helpers import load_case
+    c = load_case("windows_ref")
+    for seed, W, S, kind in zip(c["seeds"], c["W"], c["S"], c["kinds"]):
+        seed, W, S = int(seed), int(W), int(S)
+        kind = int(kind) if str(kind).isdigit() else str(kind)
+        stems = synth.house_series(6000, seed=seed)
+        X, kept = windows_oracle.nilm_dataset(stems, W, S)
+        assert np.array_equal(kept, c[f"kept_{seed}"]) and len(kept) < n_windows(6000, W, S)  # NaN windows dropped
+        sc = NILMscaler(power_scaling_type=kind, appliance_scaling_type="SameAsPower")
+        Xs = sc.fit_transform(X.copy())
+        assert [float(sc.power_stat1), float(sc.power_stat2)] == c[f"stat_{seed}"].tolist()
+        assert np.array_equal(Xs[::3, 0, 0, :], c[f"x_{seed}"])            # bit for bit (float64)
+        assert np.array_equal(Xs[::7, 1, 0, ::5], c[f"app_{seed}"])
+        s1, div = sc.power_affine()
+        assert np.array_equal(windows_oracle.scale_aggregate(X, s1, div)[::3], c[f"x_{seed}"])
+        assert np.array_equal(windows_oracle.weak_labels(X), c[f"y_{seed}"])
+        assert float(np.abs(sc.inverse_transform(Xs)[:, 0, 0, :] - X[:, 0, 0, :]).max()) == float(c[f"inv_err_{seed}"])
+    with pytest.raises(AssertionError):  # the reference's default constructor fails its own assert (:37-38)
+        NILMscaler()
