@@ -1344,7 +1344,7 @@ __device__ __forceinline__ void ensemble_pred(const PostArgs& a, const double* r
     for (int j = 0; j < NS; ++j) { accf[j] = 0.f; accd[j] = 0.0; }
     // MU members per round: all their loads are in flight before the first is consumed (every round is
     // one more memory round trip on the workgroup's critical path; the host picks MU);
-    // a member that is off adds an exact +0 (clip_cam leaves a finite value, times ri = 0)
+    // a member that is off loads nothing and adds nothing
     for (int e0 = 0; e0 < a.E; e0 += MU) {
         float v[MU][NS];
         double ri[MU];
@@ -1352,13 +1352,15 @@ __device__ __forceinline__ void ensemble_pred(const PostArgs& a, const double* r
         for (int u = 0; u < MU; ++u) {
             const int e = e0 + u < a.E ? e0 + u : 0;
             ri[u] = e0 + u < a.E ? rinv[e] : 0.0;
-            // no branch around the load (a branch makes the round's loads wait for each other): a member that
-            // is off reads the aggregate's row instead, which this workgroup has just pulled into the caches,
-            // and its values meet ri = 0 below
-            load_row<NS, VEC>(ri[u] != 0.0 ? a.cam + e * a.cam_estride + row : a.x + row, off, v[u]);
+            // a member that is off loads nothing (wave-uniform branch).  Branch-free loads that point an off member
+            // at the aggregate's row, so that a round's loads never wait for each other, measured 5 % slower.
+#pragma unroll
+            for (int j = 0; j < NS; ++j) v[u][j] = 0.f;
+            if (ri[u] != 0.0) load_row<NS, VEC>(a.cam + e * a.cam_estride + row, off, v[u]);
         }
 #pragma unroll
         for (int u = 0; u < MU; ++u) {
+            if (ri[u] == 0.0) continue;  // wave-uniform: member off
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
                 const float q = (float)((double)clip_cam(v[u][j]) * ri[u]);
