@@ -36,7 +36,7 @@ extern "C" {
 #define CAMAL_ERR_NOMEM (-4)
 
 #define CAMAL_FP32 0 /* fp32 activations, v_mfma_f32_32x32x2_f32 (exact fp32)            */
-#define CAMAL_BF16 1 /* bf16 activations/weights, v_mfma_f32_32x32x16_bf16, fp32 accumulate */
+#define CAMAL_BF16 1 /* bf16 activations/weights, v_mfma_f32_16x16x32_bf16, fp32 accumulate */
 
 typedef struct camal_ctx camal_ctx;
 
