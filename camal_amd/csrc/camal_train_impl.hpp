@@ -176,13 +176,30 @@ int t_wgrad(camal_trainer* t, hipStream_t s, const TLayer& l, const float* dz, c
     const int nsplit = wgrad_splits(t, l, B, &wps);
     const size_t need = (size_t)nsplit * l.ks * l.cout * l.cin;
     if (need > t->wg_part_floats) return fail(CAMAL_ERR_STATE, "wgrad partial buffer too small");
-    dim3 grid(l.cin / 32, (l.ks + WG_TAPS - 1) / WG_TAPS, nsplit);
-    if (l.cin == C1 && l.cout == C1)
-        hipLaunchKernelGGL((wgrad_kernel<C1, C1>), grid, dim3(C1 * 2), 0, s, dz, ain, t->wg_part, B, L, l.ks, wps);
-    else if (l.cin == C1 && l.cout == C2)
-        hipLaunchKernelGGL((wgrad_kernel<C1, C2>), grid, dim3(C2 * 2), 0, s, dz, ain, t->wg_part, B, L, l.ks, wps);
-    else
-        hipLaunchKernelGGL((wgrad_kernel<C2, C2>), grid, dim3(C2 * 2), 0, s, dz, ain, t->wg_part, B, L, l.ks, wps);
+    // whole groups of WG_TAPS taps, then one launch for the remaining (odd) 1, 3, 5 or 7
+    auto launch = [&](auto cin_c, auto cout_c) {
+        constexpr int CI = decltype(cin_c)::value, CO = decltype(cout_c)::value;
+        const int full = l.ks / WG_TAPS, rem = l.ks % WG_TAPS;
+        if (full)
+            hipLaunchKernelGGL((wgrad_kernel<CI, CO, WG_TAPS>), dim3(CI / 32, full, nsplit), dim3(CO * 2), 0, s, dz, ain,
+                               t->wg_part, B, L, l.ks, wps, 0);
+        const dim3 g(CI / 32, 1, nsplit);
+        const int tb = full * WG_TAPS;
+        switch (rem) {
+            case 0: break;
+            case 1: hipLaunchKernelGGL((wgrad_kernel<CI, CO, 1>), g, dim3(CO * 2), 0, s, dz, ain, t->wg_part, B, L, l.ks, wps, tb); break;
+            case 3: hipLaunchKernelGGL((wgrad_kernel<CI, CO, 3>), g, dim3(CO * 2), 0, s, dz, ain, t->wg_part, B, L, l.ks, wps, tb); break;
+            case 5: hipLaunchKernelGGL((wgrad_kernel<CI, CO, 5>), g, dim3(CO * 2), 0, s, dz, ain, t->wg_part, B, L, l.ks, wps, tb); break;
+            case 7: hipLaunchKernelGGL((wgrad_kernel<CI, CO, 7>), g, dim3(CO * 2), 0, s, dz, ain, t->wg_part, B, L, l.ks, wps, tb); break;
+            default: return fail(CAMAL_ERR_ARG, "kernel sizes are odd");
+        }
+        return 0;
+    };
+    int rc;
+    if (l.cin == C1 && l.cout == C1) rc = launch(std::integral_constant<int, C1>(), std::integral_constant<int, C1>());
+    else if (l.cin == C1 && l.cout == C2) rc = launch(std::integral_constant<int, C1>(), std::integral_constant<int, C2>());
+    else rc = launch(std::integral_constant<int, C2>(), std::integral_constant<int, C2>());
+    if (rc) return rc;
     const int total = l.cout * l.cin * l.ks;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gs_blocks(total, 1024)), dim3(256), 0, s, t->wg_part, nsplit, l.cout, l.cin,
                        l.ks, grads + l.w);

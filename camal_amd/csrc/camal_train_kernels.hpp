@@ -375,23 +375,26 @@ __global__ __launch_bounds__(256) void fold_edges_kernel(const float* __restrict
 #define WG_TAPS 8
 #define WG_TT 64
 
-template <int CIN, int COUT>
+// NTAP (taps of this launch's groups) is a template parameter: with a run-time count every MFMA sat behind its
+// own branch, LDS read and lgkmcnt(0) (the kernel ran at 0.32 of the fp32 peak); j0 = tap_base + blockIdx.y * NTAP.
+template <int CIN, int COUT, int NTAP>
 __global__ __launch_bounds__(COUT * 2) void wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ ain,
                                                          float* __restrict__ part, int B, int L, int ks,
-                                                         int windows_per_split) {
+                                                         int windows_per_split, int tap_base) {
     constexpr int NW = COUT / 32;
     __shared__ float s_dz[WG_TT][COUT];
     __shared__ float s_a[WG_TT + 64][32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int ci0 = blockIdx.x * 32;
-    const int j0 = blockIdx.y * WG_TAPS, ntap = min(WG_TAPS, ks - j0);
+    constexpr int ntap = NTAP;
+    const int j0 = tap_base + blockIdx.y * NTAP;
     const int split = blockIdx.z, pad = ks >> 1;
     const int b0 = split * windows_per_split, b1 = min(B, b0 + windows_per_split);
 
-    f32x16 acc[WG_TAPS];
+    f32x16 acc[NTAP];
 #pragma unroll
-    for (int j = 0; j < WG_TAPS; ++j)
+    for (int j = 0; j < NTAP; ++j)
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[j][k] = 0.f;
 
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(COUT * 2) void wgrad_kernel(const float* __restrict
                 *reinterpret_cast<float4*>(&s_dz[row][c4]) = v;
             }
             // input rows t0 + j0 - pad .. (+ TT + ntap - 2), clamped = replicate padding, 32 channels
-            for (int q = threadIdx.x; q < (WG_TT + WG_TAPS - 1) * 8; q += COUT * 2) {
+            for (int q = threadIdx.x; q < (WG_TT + NTAP - 1) * 8; q += COUT * 2) {
                 const int row = q >> 3, c4 = (q & 7) * 4;
                 int p = t0 + j0 - pad + row;
                 p = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
@@ -415,19 +418,18 @@ __global__ __launch_bounds__(COUT * 2) void wgrad_kernel(const float* __restrict
                     *reinterpret_cast<const float4*>(ain + ((size_t)b * L + p) * CIN + ci0 + c4);
             }
             __syncthreads();
-#pragma unroll 2
+#pragma unroll 4
             for (int s = 0; s < WG_TT / 2; ++s) {
                 const float av = s_dz[2 * s + h][32 * wave + i];
 #pragma unroll
-                for (int j = 0; j < WG_TAPS; ++j)
-                    if (j < ntap) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s_a[2 * s + h + j][i], acc[j], 0, 0, 0);
+                for (int j = 0; j < NTAP; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s_a[2 * s + h + j][i], acc[j], 0, 0, 0);
             }
         }
     }
     // acc[j][reg]: column ci = ci0 + i, row co = 32 wave + (reg&3) + 8 (reg>>2) + 4 h
 #pragma unroll
-    for (int j = 0; j < WG_TAPS; ++j)
-        if (j < ntap) {
+    for (int j = 0; j < NTAP; ++j) {
             float* po = part + (((size_t)split * ks + (j0 + j)) * COUT + 32 * wave) * CIN + ci0 + i;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) po[(size_t)((reg & 3) + 8 * (reg >> 2) + 4 * h) * CIN] = acc[j][reg];
