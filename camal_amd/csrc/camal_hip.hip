@@ -283,11 +283,12 @@ struct ProfScope {
 // ---- launches -------------------------------------------------------------------------
 // L_out: output rows per window; input rows per window L_in, input row for (t, tap j) = t + j - in_off;
 // zero_row == nullptr: out-of-range rows replicate the edge (forward), else they read zeros (dgrad).
-template <typename DT, int CIN, int COUT, int NWC, bool RELU, bool HAS_RES, bool HEAD>
+// NTX != 0 overrides the column tiles per wave (narrower time tile for first-kernel sizes whose halo does not fit)
+template <typename DT, int CIN, int COUT, int NWC, bool RELU, bool HAS_RES, bool HEAD, int NTX = 0>
 int launch_conv_w(camal_ctx* c, int num_cu, size_t lds_per_cu, int cam_row, hipStream_t s, const void* wpack,
                   const float* bias, int ks, const void* in, const void* res, void* out, const float* wfc, float* cam,
                   float* part, int BC, int L_out, int L_in, int in_off, const void* zero_row, float* cmax = nullptr) {
-    using G = GeomW<DT, CIN, COUT, NWC>;
+    using G = ConvGeom<DT, CIN, COUT, NTX ? NTX : TileNT<DT, CIN, COUT>::NT, NWC>;
     auto kern = conv_kernel<DT, CIN, COUT, G::TN / (32 * G::NG), NWC, RELU, HAS_RES, HEAD>;
     const size_t lds = 2 * (size_t)G::buf_bytes(ks) + (HEAD ? G::HEAD_BYTES : 0);
     if (lds > lds_per_cu) return fail(CAMAL_ERR_ARG, "kernel size too large for the LDS tile");
@@ -316,9 +317,16 @@ int launch_conv_ex(camal_ctx* c, int num_cu, size_t lds_per_cu, int cam_row, hip
     if (use_small_wg<DT, CIN, COUT, HEAD>(lds_per_cu, ks))
         return launch_conv_w<DT, CIN, COUT, 4, RELU, HAS_RES, HEAD>(c, num_cu, lds_per_cu, cam_row, s, wpack, bias, ks, in, res,
                                                                     out, wfc, cam, part, BC, L_out, L_in, in_off, zero_row, cmax);
-    if constexpr (sizeof(DT) == 4)
-        return launch_conv_w<DT, CIN, COUT, 8, RELU, HAS_RES, HEAD>(c, num_cu, lds_per_cu, cam_row, s, wpack, bias, ks, in, res,
-                                                                    out, wfc, cam, part, BC, L_out, L_in, in_off, zero_row, cmax);
+    if constexpr (sizeof(DT) == 4) {
+        using G8 = GeomW<DT, CIN, COUT, 8>;
+        if (2 * (size_t)G8::buf_bytes(ks) + (HEAD ? G8::HEAD_BYTES : 0) <= lds_per_cu || HEAD || TileNT<DT, CIN, COUT>::NT == 1)
+            return launch_conv_w<DT, CIN, COUT, 8, RELU, HAS_RES, HEAD>(c, num_cu, lds_per_cu, cam_row, s, wpack, bias, ks, in,
+                                                                        res, out, wfc, cam, part, BC, L_out, L_in, in_off, zero_row, cmax);
+        // kernel sizes past 33 on 128 channels: one column tile per wave (64-step tiles)
+        if constexpr (!HEAD && TileNT<DT, CIN, COUT>::NT != 1)
+            return launch_conv_w<DT, CIN, COUT, 8, RELU, HAS_RES, HEAD, 1>(c, num_cu, lds_per_cu, cam_row, s, wpack, bias, ks, in,
+                                                                           res, out, wfc, cam, part, BC, L_out, L_in, in_off, zero_row, cmax);
+    }
     return fail(CAMAL_ERR_ARG, "kernel size too large for the LDS tile");
 }
 

@@ -83,6 +83,26 @@ def test_fp32_vs_oracle_ragged_lengths(torch_cuda, L):
     ens.close()
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_extreme_kernel_sizes_vs_oracle(torch_cuda, precision):
+    """The C ABI admits odd first-kernel sizes 1..63: k = 1 (a 1x1 first conv), 31 and 63 (fused block tiles no
+    longer fit the LDS for the largest: per-layer kernels, weight ring past the last out-channel tile)."""
+    from camal_amd import synth, weights
+    from camal_amd.engine import Ensemble
+    from oracle import camal_oracle as oracle
+    ks = (1, 31, 63)
+    sds = [weights.make_state_dict(k, seed=8, head_gain=3.0) for k in ks]
+    x = synth.ukdale_windows(3, 300, seed=21)
+    ens = Ensemble(sds, device="cuda:0", precision=precision)
+    logits, cam = ens.forward_cam(x)
+    tol = REL_TOL_FP32 if precision == "fp32" else 5e-2
+    for e, sd in enumerate(sds):
+        cams, _labels, probs = oracle.cam_batch(sd, x, 1)
+        assert rel_err(cam[e].cpu().numpy(), cams) < tol, (ks[e], rel_err(cam[e].cpu().numpy(), cams))
+        assert np.abs(_softmax(logits[e].cpu().numpy()) - probs).max() < tol
+    ens.close()
+
+
 def test_chunking_is_invisible(torch_cuda):
     """B larger than the internal chunk gives the same numbers as one pass."""
     from camal_amd import synth, weights
