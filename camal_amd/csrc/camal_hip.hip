@@ -86,7 +86,7 @@ struct ProfRec { int cls; hipEvent_t a, b; };
 }  // namespace
 
 struct camal_ctx {
-    int device = 0, E = 0, precision = 0, chunk = 256, cam_row = 1;
+    int device = 0, E = 0, precision = 0, chunk = 0 /* 0: auto_chunk(L) */, cam_row = 1;
     int post_windows = 4096;  // windows per post-processing launch (their CAM rows wait in the workspace)
     int num_cu = 256;
     size_t lds_per_cu = 160 * 1024;
@@ -463,6 +463,14 @@ int run_member_any(camal_ctx* c, hipStream_t s, const Member& m, const float* x,
     return 0;
 }
 
+// Windows per conv pass when the caller has not set one: about 2 M timesteps (measured optimum on 1440- and
+// 10080-step windows: enough tiles to amortise launch and tail, activations of a pass still mostly on-die
+// between the block kernels), at most 1024 windows.
+int auto_chunk(const camal_ctx* c, int L) {
+    if (c->chunk > 0) return c->chunk;
+    return (int)std::max<long long>(16, std::min<long long>(1024, (1LL << 21) / std::max(1, L)));
+}
+
 int check_ctx(camal_ctx* c, int B, int L) {
     if (!c) return fail(CAMAL_ERR_ARG, "null context");
     if (B < 1 || L < 1) return fail(CAMAL_ERR_ARG, "B and L must be >= 1");
@@ -606,7 +614,7 @@ int camal_forward_cam(camal_ctx* c, const float* x, int B, int L, int member, in
     if (!x || !logits) return fail(CAMAL_ERR_ARG, "x_dev and logits_dev are required");
     if (member < -1 || member >= c->E) return fail(CAMAL_ERR_ARG, "member index out of range");
     hipStream_t s = (hipStream_t)stream;
-    const int BC = std::min(B, c->chunk);
+    const int BC = std::min(B, auto_chunk(c, L));
     Workspace w;
     if (int r = ensure_workspace(c, BC, BC, L, &w)) return r;
     const int e0 = member < 0 ? 0 : member, e1 = member < 0 ? c->E : member + 1, EO = e1 - e0;
@@ -650,7 +658,7 @@ int camal_localize(camal_ctx* c, const float* x, const double* x64, const int8_t
     if (gate_mode != 0 && gate_mode != 1) return fail(CAMAL_ERR_ARG, "gate_mode must be 0 or 1");
     hipStream_t s = (hipStream_t)stream;
     c->cam_row = 1;  // core.py:302-303 always asks for the CAM of label 1
-    const int BC = std::min(B, c->chunk), E = c->E;
+    const int BC = std::min(B, auto_chunk(c, L)), E = c->E;
     // windows per post-processing launch: a whole number of conv passes, at most post_windows and at most
     // 1 GiB of waiting CAM rows
     const long long fit = (1LL << 30) / ((long long)E * L * 4);

@@ -62,8 +62,9 @@ int camal_destroy(camal_ctx* ctx);
  * out into MFMA fragment order.  Replaces load_state_dict + .to(device) (core.py:391-398). */
 int camal_set_member_weights(camal_ctx* ctx, int member, const float* folded_host, size_t n_floats);
 
-/* Windows processed per internal pass (activation workspace is sized for this many windows;
- * default 256).                                                                           */
+/* Windows processed per internal pass (the activation workspace is sized for this many windows).
+ * Default when never called: about 2 M timesteps per pass, at most 1024 windows (measured optimum:
+ * 1024 windows of 1440 steps, 256 of 10080).                                                */
 int camal_set_chunk_windows(camal_ctx* ctx, int windows);
 
 /* 1 (default for bf16; fp32 defaults to 0; env CAMAL_FUSED overrides): blocks 2 and 3 of every member run as fused-block kernels (three ConvBlocks per
