@@ -665,6 +665,24 @@ __device__ __forceinline__ void store4_relu(__bf16* p, float a, float b, float c
     *reinterpret_cast<s16x4*>(p) = w;
 }
 
+// bf16 output rows in 16-byte stores: a lane holds, for the fragment pair (mi, nj = 0 / 1), 4 channels (8 bytes) of
+// column bcol and of column 16 + bcol; lanes l and l ^ 16 hold neighbouring 4-channel groups.  One
+// v_permlane16_swap per dword hands the even k-block rows the neighbour's half of column nj = 0 and the odd ones
+// the neighbour's half of column nj = 1: every lane then owns 8 consecutive channels of ONE column (the epilogue
+// of the fused blocks is store-issue bound; half as many, twice as wide stores).
+// in: x = the lane's 4 values of (mi, nj = 0), y = of (mi, nj = 1).  out: 16 bytes for column
+// 16 * (q & 1) + bcol, channels 16 mi + 4 (q & ~1) .. + 7, q = lane >> 4.
+__device__ __forceinline__ u32x4 pair_rows_bf16(const float (&x)[4], const float (&y)[4]) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const bf16x4 bx = {(__bf16)x[0], (__bf16)x[1], (__bf16)x[2], (__bf16)x[3]};
+    const bf16x4 by = {(__bf16)y[0], (__bf16)y[1], (__bf16)y[2], (__bf16)y[3]};
+    const u32x2 ux = __builtin_bit_cast(u32x2, bx), uy = __builtin_bit_cast(u32x2, by);
+    const u32x2 r0 = __builtin_amdgcn_permlane16_swap(ux[0], uy[0], false, false);
+    const u32x2 r1 = __builtin_amdgcn_permlane16_swap(ux[1], uy[1], false, false);
+    u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+    return o;
+}
+
 // The accumulators of a layer start from its (BN-folded) bias, read from the LDS copy `cst` of the bias vector:
 // the epilogue is then a bare relu, and no vector-memory load sits between a K loop and its epilogue.
 template <typename DT, int NT>
@@ -960,16 +978,36 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
                     if (HAS_RES) load4(cst + 384 + 32 * mt + F::chan(g, le), bv[g]);
                     else bv[g][0] = bv[g][1] = bv[g][2] = bv[g][3] = 0.f;
                 }
+                if constexpr (sizeof(DT) == 2) {
+                    const int q = le >> 4;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+                    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int c = colw + nt * 32 + F::col(g, le);
-                        const int p = t0 - 4 + c;
-                        if (c >= 4 && c < 4 + T && p < L)
-                            store4(outp + ((size_t)b * L + p) * 128 + 32 * mt + F::chan(g, le), acc[m][nt].get(g, 0) + bv[g][0],
-                                   acc[m][nt].get(g, 1) + bv[g][1], acc[m][nt].get(g, 2) + bv[g][2], acc[m][nt].get(g, 3) + bv[g][3]);
-                    }
+                        for (int mi = 0; mi < 2; ++mi) {
+                            float vx[4], vy[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                vx[i] = acc[m][nt].get(2 * mi, i) + bv[2 * mi][i];
+                                vy[i] = acc[m][nt].get(2 * mi + 1, i) + bv[2 * mi + 1][i];
+                            }
+                            const u32x4 o = pair_rows_bf16(vx, vy);
+                            const int c = colw + nt * 32 + F::col(q & 1, le);
+                            const int p = t0 - 4 + c;
+                            if (c >= 4 && c < 4 + T && p < L)
+                                *reinterpret_cast<u32x4*>(outp + ((size_t)b * L + p) * 128 + 32 * mt + 16 * mi + 4 * (q & ~1)) = o;
+                        }
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int c = colw + nt * 32 + F::col(g, le);
+                            const int p = t0 - 4 + c;
+                            if (c >= 4 && c < 4 + T && p < L)
+                                store4(outp + ((size_t)b * L + p) * 128 + 32 * mt + F::chan(g, le), acc[m][nt].get(g, 0) + bv[g][0],
+                                       acc[m][nt].get(g, 1) + bv[g][1], acc[m][nt].get(g, 2) + bv[g][2], acc[m][nt].get(g, 3) + bv[g][3]);
+                        }
+                }
             }
         } else {
 #pragma unroll
@@ -1169,20 +1207,43 @@ __global__ __launch_bounds__(512) void block1_kernel(Block1Args a, const float* 
                 load4(cst + 192 + 32 * mt + F::chan(g, le), br[g]);
             }
             DT* outp = reinterpret_cast<DT*>(a.out);
+            if constexpr (sizeof(DT) == 2) {
+                const int q = le >> 4;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int cx = colw + nt * 32 + F::col(0, le);  // the lane's columns of nj = 0 and (cx + 16) of nj = 1
+                    const float xv0 = xc[cx + pad1], xv1 = xc[cx + 16 + pad1];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c = colw + nt * 32 + F::col(g, le);
-                    const int p = t0 - 4 + c;
-                    if (c >= 4 && c < 4 + T && p < L) {
-                        const float xv = xc[c + pad1];
-                        float v[4];
+                    for (int mi = 0; mi < 2; ++mi) {
+                        float vx[4], vy[4];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = fmaxf(acc[0][nt].get(g, i), 0.f) + fmaf(wr[g][i], xv, br[g][i]);
-                        store4(outp + ((size_t)b * L + p) * 64 + 32 * mt + F::chan(g, le), v[0], v[1], v[2], v[3]);
+                        for (int i = 0; i < 4; ++i) {
+                            vx[i] = fmaxf(acc[0][nt].get(2 * mi, i), 0.f) + fmaf(wr[2 * mi][i], xv0, br[2 * mi][i]);
+                            vy[i] = fmaxf(acc[0][nt].get(2 * mi + 1, i), 0.f) + fmaf(wr[2 * mi + 1][i], xv1, br[2 * mi + 1][i]);
+                        }
+                        const u32x4 o = pair_rows_bf16(vx, vy);
+                        const int c = cx + 16 * (q & 1);
+                        const int p = t0 - 4 + c;
+                        if (c >= 4 && c < 4 + T && p < L)
+                            *reinterpret_cast<u32x4*>(outp + ((size_t)b * L + p) * 64 + 32 * mt + 16 * mi + 4 * (q & ~1)) = o;
                     }
                 }
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int c = colw + nt * 32 + F::col(g, le);
+                        const int p = t0 - 4 + c;
+                        if (c >= 4 && c < 4 + T && p < L) {
+                            const float xv = xc[c + pad1];
+                            float v[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] = fmaxf(acc[0][nt].get(g, i), 0.f) + fmaf(wr[g][i], xv, br[g][i]);
+                            store4(outp + ((size_t)b * L + p) * 64 + 32 * mt + F::chan(g, le), v[0], v[1], v[2], v[3]);
+                        }
+                    }
+            }
         }
 #pragma unroll
         for (int u = 0; u < XPT; ++u)
