@@ -379,11 +379,11 @@ int launch_block(camal_ctx* c, hipStream_t s, const Layer& l1, const Layer& l2, 
 }
 
 // fused block 1: x [BC][L] -> block output [BC][L][64]
-template <typename DT>
-int launch_block1(camal_ctx* c, hipStream_t s, const Member& m, const float* x, void* out, int BC, int L) {
-    constexpr int NTB = sizeof(DT) == 2 ? 4 : 2;  // 512-column tiles in bf16, 256 in fp32 (LDS)
-    using G = Block1Geom<DT, NTB>;
-    auto kern = block1_kernel<DT, NTB>;
+template <typename DT, int NWC>
+int launch_block1_w(camal_ctx* c, hipStream_t s, const Member& m, const float* x, void* out, int BC, int L) {
+    constexpr int NTB = sizeof(DT) == 2 ? 4 : 2;  // column tiles per wave
+    using G = Block1Geom<DT, NTB, NWC>;
+    auto kern = block1_kernel<DT, NTB, NWC>;
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
@@ -404,6 +404,13 @@ int launch_block1(camal_ctx* c, hipStream_t s, const Member& m, const float* x, 
     hipLaunchKernelGGL(kern, dim3(grid), dim3(G::THREADS), G::LDS_BYTES, s, a, m.stem_w, m.stem_b, m.res1_w, m.res1_b);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+// 8 waves, one workgroup per CU.  (Two 4-wave workgroups of half the tile width per CU, so that one's VALU stem
+// runs under the other's MFMAs: measured, no difference.)
+template <typename DT>
+int launch_block1(camal_ctx* c, hipStream_t s, const Member& m, const float* x, void* out, int BC, int L) {
+    return launch_block1_w<DT, 8>(c, s, m, x, out, BC, L);
 }
 
 // One member's conv stack on BC windows: x -> cam row 1 [BC][L] + pooled partials [BC][ntiles][2]

@@ -744,12 +744,15 @@ __device__ __forceinline__ void fix_edges(char* buf, int guard, int g, int c_fir
 
 #ifdef CAMAL_STAMPS
 // Diagnostic build only: s_memtime stamps of the second tile of every workgroup (block 3 kernel), per wave.
-#define CAMAL_NSTAMP 16
+#define CAMAL_NSTAMP 18
 __device__ unsigned long long g_stamps[256][9][CAMAL_NSTAMP];
 #define STAMP(i) do { if (HEAD && it == 1 && blockIdx.x < 256 && (threadIdx.x & 63) == 0) \
     g_stamps[blockIdx.x][threadIdx.x >> 6][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP1(i) do { if (it == 1 && blockIdx.x < 256 && (threadIdx.x & 63) == 0) \
+    g_stamps[blockIdx.x][threadIdx.x >> 6][10 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(i) do {} while (0)
+#define STAMP1(i) do {} while (0)
 #endif
 
 struct BlockArgs {
@@ -1073,10 +1076,10 @@ struct Block1Args {
     int L, ks1, tiles_per_window, total_tiles;
 };
 
-template <typename DT, int NT>
+template <typename DT, int NT, int NWC = 8>
 struct Block1Geom {
     static constexpr int ES = sizeof(DT);
-    static constexpr int NWC = 8, THREADS = NWC * 64;
+    static constexpr int THREADS = NWC * 64;
     static constexpr int N = (NWC / 2) * 32 * NT;   // computed columns per tile
     static constexpr int T = N - 8;
     static constexpr int RB = 64 * ES;              // activation row bytes
@@ -1087,11 +1090,13 @@ struct Block1Geom {
     static constexpr int LDS_BYTES = CST_OFF + 4 * 64 * 4;
 };
 
-template <typename DT, int NT>
-__global__ __launch_bounds__(512) void block1_kernel(Block1Args a, const float* __restrict__ stem_w /*[k][64]*/,
+// NWC = 8: one workgroup per CU, 512-column tiles (bf16).  NWC = 4: half the tile, two workgroups per CU.
+template <typename DT, int NT, int NWC>
+__global__ __launch_bounds__(NWC * 64) void block1_kernel(Block1Args a, const float* __restrict__ stem_w /*[k][64]*/,
                                                      const float* __restrict__ stem_b, const float* __restrict__ res_w,
                                                      const float* __restrict__ res_b) {
-    using G = Block1Geom<DT, NT>;
+    using G = Block1Geom<DT, NT, NWC>;
+    constexpr int TH = G::THREADS;
     constexpr int N = G::N, T = G::T, NCP = 64 / Elem<DT>::K_PER_PAIR;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     char* A1 = lds;
@@ -1116,11 +1121,11 @@ __global__ __launch_bounds__(512) void block1_kernel(Block1Args a, const float* 
         cst[128 + i] = res_w[i];
         cst[192 + i] = res_b[i];
     }
-    constexpr int XPT = (G::XS + 511) / 512;  // x values per thread
+    constexpr int XPT = (G::XS + TH - 1) / TH;  // x values per thread
     if ((int)blockIdx.x < a.total_tiles)
 #pragma unroll
         for (int u = 0; u < XPT; ++u)
-            if ((int)threadIdx.x + 512 * u < nx) xs[threadIdx.x + 512 * u] = load_x(blockIdx.x, threadIdx.x + 512 * u);
+            if ((int)threadIdx.x + TH * u < nx) xs[threadIdx.x + TH * u] = load_x(blockIdx.x, threadIdx.x + TH * u);
     __syncthreads();
 
     // stem role: channel half sh, 64 columns;  MFMA role: channel tile mt, NT column tiles
@@ -1146,9 +1151,10 @@ __global__ __launch_bounds__(512) void block1_kernel(Block1Args a, const float* 
 #pragma unroll
         for (int u = 0; u < XPT; ++u) {
             xpre[u] = 0.f;
-            if (next < a.total_tiles && (int)threadIdx.x + 512 * u < nx) xpre[u] = load_x(next, threadIdx.x + 512 * u);
+            if (next < a.total_tiles && (int)threadIdx.x + TH * u < nx) xpre[u] = load_x(next, threadIdx.x + TH * u);
         }
 
+        STAMP1(0);
         // ---- ConvBlock(k), 1 -> 64, VALU: a1[c][co] = relu(b[co] + sum_j w[j][co] x[c + j])  -> A1 row c + 3
         {
             float sacc[SC][32];
@@ -1180,15 +1186,18 @@ __global__ __launch_bounds__(512) void block1_kernel(Block1Args a, const float* 
                 }
             }
         }
+        STAMP1(1);
         __syncthreads();
         if (lo || hi) {
             if (wave == 0) fix_edges<DT, 64>(A1, 3, 3, c_first, c_last, lo, hi, lane);
             __syncthreads();
         }
+        STAMP1(2);
         F acc[1][NT];
         // ---- ConvBlock(7): A1 -> A2, rows = column + 1   (accumulators start from the bias)
         init_acc_bias<DT, NT>(acc[0], cst, mt, lane);
         mma_layer<DT, 64, NT, 1>(A1, colw, 7, w2, acc);
+        STAMP1(3);
         store_act_lds<DT, NT, 64>(A2, colw + 1, acc[0], mt, opaque(lane));
         __syncthreads();
         if (lo || hi) {
@@ -1196,8 +1205,10 @@ __global__ __launch_bounds__(512) void block1_kernel(Block1Args a, const float* 
             __syncthreads();
         }
         // ---- ConvBlock(3): A2 -> registers; out = relu(. + b3) + (wr x + br)   (skip added after the ReLU)
+        STAMP1(4);
         init_acc_bias<DT, NT>(acc[0], cst + 64, mt, lane);
         mma_layer<DT, 64, NT, 1>(A2, colw, 3, w3, acc);
+        STAMP1(5);
         {
             float wr[4][4], br[4][4];
             const int le = opaque(lane);
@@ -1245,10 +1256,12 @@ __global__ __launch_bounds__(512) void block1_kernel(Block1Args a, const float* 
                     }
             }
         }
+        STAMP1(6);
 #pragma unroll
         for (int u = 0; u < XPT; ++u)
-            if (next < a.total_tiles && (int)threadIdx.x + 512 * u < nx) xn[threadIdx.x + 512 * u] = xpre[u];
+            if (next < a.total_tiles && (int)threadIdx.x + TH * u < nx) xn[threadIdx.x + TH * u] = xpre[u];
         __syncthreads();  // END: A1/A2 free, next x in place
+        STAMP1(7);
     }
 }
 

@@ -13,7 +13,7 @@ for _ in range(3):
     ens.localize(x)
 torch.cuda.synchronize()
 lib = C.CDLL(os.environ["CAMAL_HIP_LIB"])
-buf = np.zeros((256, 9, 16), np.uint64)
+buf = np.zeros((256, 9, 18), np.uint64)
 assert lib.camal_debug_stamps(buf.ctypes.data_as(C.c_void_p)) == 0
 st = buf[:, :8, :10].astype(np.int64)       # compute waves
 d = np.diff(st, axis=2)                     # [wg][wave][9]
