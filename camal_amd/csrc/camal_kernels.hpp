@@ -1408,19 +1408,22 @@ __device__ __forceinline__ void load_row(const float* rowp, const unsigned (&off
 // rinv[e] = 1/max of member e, or 0 when the member adds nothing (voted off, max 0, window off): wave-uniform.
 template <int NS, bool F64, int MU, bool VEC>
 __device__ __forceinline__ void ensemble_pred(const PostArgs& a, const double* rinv, size_t row, const unsigned (&off)[NS],
-                                              const bool (&ok)[NS], double vote, double (&out)[NS]) {
+                                              const bool (&ok)[NS], double vote, double (&out)[NS],
+                                              bool do_halo, unsigned hoff, bool hok, double& hout) {
     // off[j]: BYTE offset of the position inside the window row, already clamped into it (a position that
     // is not wanted still loads a valid address; ok[j] = false zeroes its result).  32-bit byte offsets on a
     // wave-uniform row base let the loads use the scalar-base addressing form (no 64-bit lane addresses).
-    float accf[NS];
-    double accd[NS];
+    // do_halo: this lane also computes ONE position of the moving average's halo (byte offset hoff); its loads
+    // go out in the same round as the tile's, so the halo costs no memory round trip of its own.
+    float accf[NS + 1];
+    double accd[NS + 1];
 #pragma unroll
-    for (int j = 0; j < NS; ++j) { accf[j] = 0.f; accd[j] = 0.0; }
+    for (int j = 0; j <= NS; ++j) { accf[j] = 0.f; accd[j] = 0.0; }
     // MU members per round: all their loads are in flight before the first is consumed (every round is
     // one more memory round trip on the workgroup's critical path; the host picks MU);
     // a member that is off loads nothing and adds nothing
     for (int e0 = 0; e0 < a.E; e0 += MU) {
-        float v[MU][NS];
+        float v[MU][NS + 1];
         double ri[MU];
 #pragma unroll
         for (int u = 0; u < MU; ++u) {
@@ -1429,14 +1432,21 @@ __device__ __forceinline__ void ensemble_pred(const PostArgs& a, const double* r
             // a member that is off loads nothing (wave-uniform branch).  Branch-free loads that point an off member
             // at the aggregate's row, so that a round's loads never wait for each other, measured 5 % slower.
 #pragma unroll
-            for (int j = 0; j < NS; ++j) v[u][j] = 0.f;
-            if (ri[u] != 0.0) load_row<NS, VEC>(a.cam + e * a.cam_estride + row, off, v[u]);
+            for (int j = 0; j <= NS; ++j) v[u][j] = 0.f;
+            if (ri[u] != 0.0) {
+                const float* rp = a.cam + e * a.cam_estride + row;
+                float t[NS];
+                load_row<NS, VEC>(rp, off, t);
+#pragma unroll
+                for (int j = 0; j < NS; ++j) v[u][j] = t[j];
+                if (do_halo) v[u][NS] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rp) + hoff);
+            }
         }
 #pragma unroll
         for (int u = 0; u < MU; ++u) {
             if (ri[u] == 0.0) continue;  // wave-uniform: member off
 #pragma unroll
-            for (int j = 0; j < NS; ++j) {
+            for (int j = 0; j <= NS; ++j) {
                 const float q = (float)((double)clip_cam(v[u][j]) * ri[u]);
                 if (F64) accd[j] += (double)q;
                 else accf[j] += q;
@@ -1446,9 +1456,10 @@ __device__ __forceinline__ void ensemble_pred(const PostArgs& a, const double* r
     // pred / len(models): float64 division, or the float32 one by the same float64-product argument
     const double inv_e = 1.0 / (double)a.E;
 #pragma unroll
-    for (int j = 0; j < NS; ++j) {
+    for (int j = 0; j <= NS; ++j) {
         const double avg = F64 ? accd[j] / (double)a.E : (double)(float)((double)accf[j] * inv_e);
-        out[j] = ok[j] ? avg * vote : 0.0;
+        if (j < NS) out[j] = ok[j] ? avg * vote : 0.0;
+        else hout = hok ? avg * vote : 0.0;
     }
 }
 
@@ -1558,22 +1569,20 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
         // np.convolve(p, ones(w), 'same')[t] = sum_{m = t + lo .. t + hi} p[m]: the tile needs pred on
         // [c0 + lo, c0 + n + hi)
         {
-            double pr[POST_PER_LANE];
-            if (a.pred_f64) ensemble_pred<POST_PER_LANE, true, MU, VEC>(a, rinv, row, off, ok, vote, pr);
-            else ensemble_pred<POST_PER_LANE, false, MU, VEC>(a, rinv, row, off, ok, vote, pr);
+            // halo: -lo positions before the tile, hi after it (zero outside the window), one per lane of the
+            // first w - 1 lanes, loaded in the same rounds as the tile itself
+            const bool do_halo = tid < w - 1;
+            const bool left = tid < -lo;
+            const int th = left ? c0 + lo + tid : c0 + n + (tid + lo);
+            const unsigned hoff = 4u * (unsigned)min(max(th, 0), L - 1);
+            const bool hok = th >= 0 && th < L;
+            double pr[POST_PER_LANE], hpr = 0.0;
+            if (a.pred_f64) ensemble_pred<POST_PER_LANE, true, MU, VEC>(a, rinv, row, off, ok, vote, pr, do_halo, hoff, hok, hpr);
+            else ensemble_pred<POST_PER_LANE, false, MU, VEC>(a, rinv, row, off, ok, vote, pr, do_halo, hoff, hok, hpr);
 #pragma unroll
             for (int j = 0; j < POST_PER_LANE; ++j)
                 if (ok[j]) s_pred[pos[j] - lo] = pr[j];
-        }
-        if (tid < w - 1) {  // halo: -lo positions before the tile, hi after it (zero outside the window)
-            const bool left = tid < -lo;
-            const int t = left ? c0 + lo + tid : c0 + n + (tid + lo);
-            unsigned hoff[1] = {4u * (unsigned)min(max(t, 0), L - 1)};
-            bool hok[1] = {t >= 0 && t < L};
-            double pr[1];
-            if (a.pred_f64) ensemble_pred<1, true, MU, false>(a, rinv, row, hoff, hok, vote, pr);
-            else ensemble_pred<1, false, MU, false>(a, rinv, row, hoff, hok, vote, pr);
-            s_pred[left ? tid : n + tid] = pr[0];
+            if (do_halo) s_pred[left ? tid : n + tid] = hpr;
         }
         __syncthreads();
     }
