@@ -505,7 +505,7 @@ int launch_post(camal_ctx* c, hipStream_t s, const PostArgs& a0, bool own_max) {
         a.x += o; if (a.x64) a.x64 += o; if (a.y) a.y += b0;
         if (a.prob_out) a.prob_out += b0;
         a.state_out += o; if (a.avg_out) a.avg_out += o; if (a.power_out) a.power_out += o;
-        const dim3 grid(tiles, a.B), block(256);
+        const dim3 grid(tiles, a.B), block(POST_THREADS);
         // 4 members per load round: 5 or 8 per round cost more registers (occupancy) than the round trip
         // they save (measured on E = 5)
         if (own_max) {

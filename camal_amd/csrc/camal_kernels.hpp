@@ -1299,8 +1299,11 @@ __global__ void logits_kernel(const float* __restrict__ part, const float* __res
 // the caller brought) scans the window's rows for it instead.
 // ---------------------------------------------------------------------------------------
 #define CAMAL_MAX_MEMBERS 16
-#define POST_TILE 1024
-#define POST_PER_LANE (POST_TILE / 256)
+#ifndef POST_THREADS
+#define POST_THREADS 128
+#endif
+#define POST_PER_LANE 4
+#define POST_TILE (POST_THREADS * POST_PER_LANE)
 
 struct PostArgs {
     const float* cam;      // member e, window b: cam + e*cam_estride + b*L
@@ -1469,13 +1472,13 @@ __device__ __forceinline__ void ensemble_pred(const PostArgs& a, const double* r
 // OWN_MAX = true (camal_postprocess on rows and logits the caller brought): softmax, vote and a scan of the
 //   window's rows for their maxima in the kernel.
 // VEC: L % 4 == 0, every lane works on 4 consecutive timesteps through 16-byte loads and stores; else lane t of
-//   the tile takes timesteps t, t + 256, ... through dwords.
+//   the tile takes timesteps t, t + POST_THREADS, ... through dwords.
 template <bool OWN_MAX, int MU, bool VEC>
-__global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
+__global__ __launch_bounds__(POST_THREADS) void post_kernel(PostArgs a) {
     __shared__ double s_rinv[OWN_MAX ? CAMAL_MAX_MEMBERS : 1];
     __shared__ float s_p1[OWN_MAX ? CAMAL_MAX_MEMBERS : 1];
     __shared__ int s_lab[OWN_MAX ? CAMAL_MAX_MEMBERS : 1];
-    __shared__ float s_red[4];
+    __shared__ float s_red[POST_THREADS / 64];
     __shared__ int s_y;
     __shared__ double s_pred[POST_TILE + 64];
     const int b = blockIdx.y, c0 = blockIdx.x * POST_TILE, L = a.L, E = a.E;
@@ -1489,7 +1492,7 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
     bool ok[POST_PER_LANE];
 #pragma unroll
     for (int j = 0; j < POST_PER_LANE; ++j) {
-        pos[j] = VEC ? 4 * tid + j : tid + 256 * j;
+        pos[j] = VEC ? 4 * tid + j : tid + POST_THREADS * j;
         ok[j] = pos[j] < n;
         // VEC: n is a multiple of 4, a lane is in or out as a whole; an idle lane re-reads the tile's first chunk
         off[j] = 4u * (unsigned)(c0 + (VEC ? (ok[0] ? pos[j] : j) : min(pos[j], n - 1)));
@@ -1540,7 +1543,7 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
             float m = 0.f;
             if (pass && s_lab[e]) {
                 const float* c = a.cam + e * a.cam_estride + row;
-                for (int t = tid; t < L; t += 256) m = fmaxf(m, clip_cam(c[t]));
+                for (int t = tid; t < L; t += POST_THREADS) m = fmaxf(m, clip_cam(c[t]));
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
             }
@@ -1548,7 +1551,9 @@ __global__ __launch_bounds__(256) void post_kernel(PostArgs a) {
             if (lane == 0) s_red[wave] = m;
             __syncthreads();
             if (tid == 0) {
-                const float mm = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+                float mm = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < POST_THREADS / 64; ++wv) mm = fmaxf(mm, s_red[wv]);
                 s_rinv[e] = mm > 0.f ? 1.0 / (double)mm : 0.0;
             }
         }
