@@ -509,11 +509,11 @@ int launch_post(camal_ctx* c, hipStream_t s, const PostArgs& a0, bool own_max) {
         // 4 members per load round: 5 or 8 per round cost more registers (occupancy) than the round trip
         // they save (measured on E = 5)
         if (own_max) {
-            if (vec) hipLaunchKernelGGL((post_kernel<true, 4, true>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((post_kernel<true, 4, false>), grid, block, 0, s, a);
+            if (vec) hipLaunchKernelGGL((post_kernel<true, POST_MU, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((post_kernel<true, POST_MU, false>), grid, block, 0, s, a);
         } else {
-            if (vec) hipLaunchKernelGGL((post_kernel<false, 4, true>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((post_kernel<false, 4, false>), grid, block, 0, s, a);
+            if (vec) hipLaunchKernelGGL((post_kernel<false, POST_MU, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((post_kernel<false, POST_MU, false>), grid, block, 0, s, a);
         }
         HIP_TRY(hipGetLastError());
     }

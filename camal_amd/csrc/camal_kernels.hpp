@@ -1303,6 +1303,9 @@ __global__ void logits_kernel(const float* __restrict__ part, const float* __res
 #define POST_THREADS 128
 #endif
 #define POST_PER_LANE 4
+#ifndef POST_MU
+#define POST_MU 4  // members per load round
+#endif
 #define POST_TILE (POST_THREADS * POST_PER_LANE)
 
 struct PostArgs {
