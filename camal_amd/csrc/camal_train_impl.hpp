@@ -126,7 +126,7 @@ int t_bn_stats(camal_trainer* t, hipStream_t s, const float* z, int N, const TLa
                float* running) {
     const int nb = (N + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK;
     hipLaunchKernelGGL(bn_stats_partial_kernel<C>, dim3(nb), dim3(256), 0, s, z, N, t->partial);
-    hipLaunchKernelGGL(bn_stats_final_kernel<C>, dim3(1), dim3(BN_FINAL_THREADS), 0, s, t->partial, nb, N, eps, momentum,
+    hipLaunchKernelGGL(bn_stats_final_kernel<C>, dim3(C / BN_FINAL_CPB), dim3(BN_FINAL_THREADS), 0, s, t->partial, nb, N, eps, momentum,
                        t->mean + l.zi * 128, t->invstd + l.zi * 128, running ? running + l.rm : nullptr,
                        running ? running + l.rv : nullptr);
     HIP_TRY(hipGetLastError());
@@ -160,7 +160,7 @@ int t_bn_bwd(camal_trainer* t, hipStream_t s, const float* params, float* grads,
     const float inv_len = 1.f / (float)L;
     hipLaunchKernelGGL((bn_bwd_partial_kernel<C, RELU, BCAST>), dim3(nb), dim3(256), 0, s, da, z, mean, invstd,
                        params + l.g, params + l.be, N, L, inv_len, t->partial);
-    hipLaunchKernelGGL(bn_bwd_final_kernel<C>, dim3(1), dim3(BN_FINAL_THREADS), 0, s, t->partial, nb, t->s1, t->s2, grads + l.g,
+    hipLaunchKernelGGL(bn_bwd_final_kernel<C>, dim3(C / BN_FINAL_CPB), dim3(BN_FINAL_THREADS), 0, s, t->partial, nb, t->s1, t->s2, grads + l.g,
                        grads + l.be);
     hipLaunchKernelGGL((bn_bwd_apply_kernel<C, RELU, BCAST>), dim3(gs_blocks((size_t)N * (C / 4))), dim3(256), 0, s, da, z,
                        mean, invstd, params + l.g, params + l.be, t->s1, t->s2, N, L, inv_len, dz);

@@ -113,28 +113,39 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     }
 }
 
-// Stage 2, one workgroup: BN_FINAL_THREADS / C lanes per channel each sum a fixed strided subset of the
-// partials, then a fixed-order combine through LDS (deterministic, and short dependent chains: a single
-// lane per channel walking every partial was 60 us of pure load latency per BatchNorm).
+// Stage 2, C / BN_FINAL_CPB workgroups of BN_FINAL_CPB channels each: BN_FINAL_THREADS / BN_FINAL_CPB lanes per
+// channel each sum a fixed strided subset of the partials, then a fixed-order combine (xor shuffles inside the
+// wave, LDS across the waves), so the result does not depend on scheduling.  One workgroup for all channels
+// took 17 us per BatchNorm: 2 MB of partials through a single CU's load path; a single lane per channel
+// walking every partial was 60 us of load latency.
+#define BN_FINAL_CPB 8
 template <int C>
-__device__ __forceinline__ void bn_final_reduce(const double* __restrict__ partial, int nblocks, double& a, double& b) {
-    constexpr int G = BN_FINAL_THREADS / C;
-    __shared__ double sh[BN_FINAL_THREADS][2];
-    const int c = threadIdx.x % C, g = threadIdx.x / C;
+__device__ __forceinline__ bool bn_final_reduce(const double* __restrict__ partial, int nblocks, int& c, double& a, double& b) {
+    constexpr int G = BN_FINAL_THREADS / BN_FINAL_CPB, NW = BN_FINAL_THREADS / 64;
+    static_assert(C % BN_FINAL_CPB == 0 && 64 % BN_FINAL_CPB == 0, "channels per workgroup");
+    __shared__ double sh[NW][BN_FINAL_CPB][2];
+    const int cl = threadIdx.x % BN_FINAL_CPB, g = threadIdx.x / BN_FINAL_CPB;
+    c = blockIdx.x * BN_FINAL_CPB + cl;
     double s = 0.0, ss = 0.0;
 #pragma unroll 4
     for (int i = g; i < nblocks; i += G) {
-        s += partial[((size_t)i * C + c) * 2];
-        ss += partial[((size_t)i * C + c) * 2 + 1];
+        const double2 t = *reinterpret_cast<const double2*>(partial + ((size_t)i * C + c) * 2);
+        s += t.x;
+        ss += t.y;
     }
-    sh[threadIdx.x][0] = s;
-    sh[threadIdx.x][1] = ss;
+#pragma unroll
+    for (int m = BN_FINAL_CPB; m < 64; m <<= 1) {
+        s += __shfl_xor(s, m, 64);
+        ss += __shfl_xor(ss, m, 64);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < BN_FINAL_CPB) { sh[wave][lane][0] = s; sh[wave][lane][1] = ss; }
     __syncthreads();
     a = 0.0; b = 0.0;
-    if (g == 0) {
+    if (threadIdx.x >= BN_FINAL_CPB) return false;
 #pragma unroll
-        for (int k = 0; k < G; ++k) { a += sh[k * C + c][0]; b += sh[k * C + c][1]; }
-    }
+    for (int k = 0; k < NW; ++k) { a += sh[k][cl][0]; b += sh[k][cl][1]; }
+    return true;
 }
 
 template <int C>
@@ -142,9 +153,8 @@ __global__ __launch_bounds__(BN_FINAL_THREADS) void bn_stats_final_kernel(
     const double* __restrict__ partial, int nblocks, int N, float eps, float momentum, float* __restrict__ mean,
     float* __restrict__ invstd, float* __restrict__ running_mean, float* __restrict__ running_var) {
     double s, ss;
-    bn_final_reduce<C>(partial, nblocks, s, ss);
-    if (threadIdx.x >= C) return;
-    const int c = threadIdx.x;
+    int c;
+    if (!bn_final_reduce<C>(partial, nblocks, c, s, ss)) return;
     const double m = s / N;
     double var = ss / N - m * m;
     var = var > 0.0 ? var : 0.0;
@@ -223,9 +233,8 @@ __global__ __launch_bounds__(BN_FINAL_THREADS) void bn_bwd_final_kernel(const do
                                                                         float* __restrict__ dgamma,
                                                                         float* __restrict__ dbeta) {
     double a, b;
-    bn_final_reduce<C>(partial, nblocks, a, b);
-    if (threadIdx.x >= C) return;
-    const int c = threadIdx.x;
+    int c;
+    if (!bn_final_reduce<C>(partial, nblocks, c, a, b)) return;
     s1[c] = (float)a;
     s2[c] = (float)b;
     dbeta[c] = (float)a;
