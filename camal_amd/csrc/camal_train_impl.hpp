@@ -209,9 +209,9 @@ int t_wgrad(camal_trainer* t, hipStream_t s, const TLayer& l, const float* dz, c
 }
 
 int t_stem_wgrad(camal_trainer* t, hipStream_t s, const TLayer& l, const float* dz, const float* x, float* grads, int B, int L) {
-    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(B), dim3(256), 0, s, dz, x, t->stem_part, L, l.ks);
-    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((64 * l.ks + 255) / 256), dim3(256), 0, s, t->stem_part, B, l.ks,
-                       grads + l.w);
+    const int nseg = stem_nseg(L);
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(B, nseg), dim3(256), 0, s, dz, x, t->stem_part, L, l.ks);
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(l.ks), dim3(256), 0, s, t->stem_part, B * nseg, l.ks, grads + l.w);
     hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(128), 0, s, grads + l.b, (size_t)l.cout, 0.f);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -286,7 +286,7 @@ int camal_trainer_create(int device_id, int kernel_size, int max_batch, int max_
     const int pad_max = std::max(kernel_size >> 1, 3);
     A(&t->gA, N * C2); A(&t->gB, N * C2); A(&t->gZ, N * C2); A(&t->gZr, N * C2);
     A(&t->gXP, (size_t)max_batch * (max_len + 2 * pad_max) * C2);
-    A(&t->stem_part, (size_t)max_batch * kernel_size * 64);
+    A(&t->stem_part, (size_t)max_batch * stem_nseg(max_len) * kernel_size * 64);
     A(&t->pooled, (size_t)max_batch * 128); A(&t->dpool, (size_t)max_batch * 128);
     A(&t->logits, (size_t)max_batch * 2); A(&t->dlogits, (size_t)max_batch * 2); A(&t->loss, (size_t)max_batch);
     if (!r) r = t_alloc(t, (void**)&t->correct, (size_t)max_batch * sizeof(int));

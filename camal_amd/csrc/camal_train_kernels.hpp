@@ -457,45 +457,60 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, 
     }
 }
 
-// Cin = 1 layers: part[b][j][co] = sum_t dz[b][t][co] * x[b][clamp(t + j - pad)]   (64 out-channels)
+// Cin = 1 layers: part[b * nseg + seg][j][co] = sum over the segment's t of dz[b][t][co] * x[b][clamp(t + j - pad)]
+// (64 out-channels).  One workgroup per (window, segment of STEM_SEG_LEN steps): a window per workgroup left half
+// the CUs idle at the batch sizes trained on, and the aggregate was re-read from global memory once per tap.
+#define STEM_SEG_LEN 128
+__host__ __device__ inline int stem_nseg(int L) { return (L + STEM_SEG_LEN - 1) / STEM_SEG_LEN; }
+
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                          float* __restrict__ part, int L, int ks) {
     __shared__ float red[4][64];
-    const int b = blockIdx.x, co = threadIdx.x & 63, ph = threadIdx.x >> 6, pad = ks >> 1;
+    __shared__ float xs[STEM_SEG_LEN + 64 + 8];
+    const int b = blockIdx.x, seg = blockIdx.y, co = threadIdx.x & 63, ph = threadIdx.x >> 6, pad = ks >> 1;
+    const int t0 = seg * STEM_SEG_LEN, t1 = min(L, t0 + STEM_SEG_LEN);
     const float* xb = x + (size_t)b * L;
     const float* dzb = dz + (size_t)b * L * 64;
+    // xs[r] = x[clamp(t0 - pad + r)]; the rows past the last tap only meet accumulators that are never stored
+    for (int r = threadIdx.x; r < STEM_SEG_LEN + 64 + 8; r += 256) {
+        int p = t0 - pad + r;
+        p = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
+        xs[r] = xb[p];
+    }
+    __syncthreads();
+    float* po = part + ((size_t)b * gridDim.y + seg) * ks * 64;
     for (int j0 = 0; j0 < ks; j0 += 8) {
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-        for (int t = ph; t < L; t += 4) {
+#pragma unroll 4
+        for (int t = t0 + ph; t < t1; t += 4) {
             const float d = dzb[(size_t)t * 64 + co];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                int p = t + j0 + j - pad;
-                p = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
-                acc[j] = fmaf(d, xb[p], acc[j]);
-            }
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(d, xs[t - t0 + j0 + j], acc[j]);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             __syncthreads();
             red[ph][co] = acc[j];
             __syncthreads();
-            if (ph == 0 && j0 + j < ks)
-                part[((size_t)b * ks + j0 + j) * 64 + co] = (red[0][co] + red[1][co]) + (red[2][co] + red[3][co]);
+            if (ph == 0 && j0 + j < ks) po[(j0 + j) * 64 + co] = (red[0][co] + red[1][co]) + (red[2][co] + red[3][co]);
         }
     }
 }
 
-// grad[co][j] = sum_b part[b][j][co]
-__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ part, int B, int ks, float* __restrict__ grad) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 64 * ks) return;
-    const int co = idx % 64, j = idx / 64;
+// grad[co][j] = sum_p part[p][j][co], one workgroup per tap: four lanes per channel walk every fourth partial
+// (independent loads), combined in a fixed order
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ part, int nparts, int ks,
+                                                                float* __restrict__ grad) {
+    __shared__ float red[4][64];
+    const int j = blockIdx.x, co = threadIdx.x & 63, g = threadIdx.x >> 6;
     float a = 0.f;
-    for (int b = 0; b < B; ++b) a += part[((size_t)b * ks + j) * 64 + co];
-    grad[co * ks + j] = a;
+#pragma unroll 8
+    for (int p = g; p < nparts; p += 4) a += part[((size_t)p * ks + j) * 64 + co];
+    red[g][co] = a;
+    __syncthreads();
+    if (g == 0) grad[co * ks + j] = (red[0][co] + red[1][co]) + (red[2][co] + red[3][co]);
 }
 
 // ---- AdamW (torch.optim.AdamW defaults: torch_trainer.py:35; decoupled weight decay) -------------------
