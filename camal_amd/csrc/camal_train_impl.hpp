@@ -103,9 +103,18 @@ int t_conv(camal_trainer* t, hipStream_t s, const float* wpack, const float* bia
                                                                    in_off, zero_row);
 }
 
-int t_pack(hipStream_t s, const float* w, float* out, int coutp, int cinp, int ks, int flip) {
-    const int total = coutp * cinp * ks;
-    hipLaunchKernelGGL(pack_w_kernel, dim3(gs_blocks(total, 1024)), dim3(256), 0, s, w, out, coutp, cinp, ks, flip);
+// wpack (forward) and wflip (data gradient) of every MFMA layer, from the step's parameters
+int t_pack_all(camal_trainer* t, hipStream_t s, const float* params, bool backward) {
+    PackJobs jobs;
+    int n = 0, biggest = 0;
+    auto add = [&](const TLayer& l, float* fwd, float* flip) {
+        jobs.j[n++] = PackJob{params + l.w, fwd, l.cout, l.cin, l.ks, 0};
+        if (backward) jobs.j[n++] = PackJob{params + l.w, flip, /*cout'=*/l.cin, /*cin'=*/l.cout, l.ks, 1};
+        biggest = std::max(biggest, l.cout * l.cin * l.ks);
+    };
+    for (int i = 1; i < 9; ++i) add(t->lay.conv[i], t->wpack[i], t->wflip[i]);
+    add(t->lay.res[1], t->wpack_res2, t->wflip_res2);
+    hipLaunchKernelGGL(pack_w_kernel, dim3(gs_blocks(biggest, 256), n), dim3(256), 0, s, jobs);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -113,7 +122,6 @@ int t_pack(hipStream_t s, const float* w, float* out, int coutp, int cinp, int k
 // forward conv of layer l (cin >= 64): pack weights, z = conv(in) + bias
 int t_conv_fwd(camal_trainer* t, hipStream_t s, const TLayer& l, const float* params, float* wpack, const float* in,
                float* zout, int B, int L) {
-    if (int r = t_pack(s, params + l.w, wpack, l.cout, l.cin, l.ks, 0)) return r;
     const float* bias = params + l.b;
     const int pad = l.ks >> 1;
     if (l.cin == C1 && l.cout == C1) return t_conv<C1, C1, false>(t, s, wpack, bias, l.ks, in, nullptr, zout, B, L, L, pad, nullptr);
@@ -201,9 +209,8 @@ int t_wgrad(camal_trainer* t, hipStream_t s, const TLayer& l, const float* dz, c
     else rc = launch(std::integral_constant<int, C2>(), std::integral_constant<int, C2>());
     if (rc) return rc;
     const int total = l.cout * l.cin * l.ks;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gs_blocks(total, 1024)), dim3(256), 0, s, t->wg_part, nsplit, l.cout, l.cin,
-                       l.ks, grads + l.w);
-    hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(128), 0, s, grads + l.b, (size_t)l.cout, 0.f);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total / 4 + 63) / 64), dim3(256), 0, s, t->wg_part, nsplit, l.cout, l.cin,
+                       l.ks, grads + l.w, grads + l.b);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -211,8 +218,8 @@ int t_wgrad(camal_trainer* t, hipStream_t s, const TLayer& l, const float* dz, c
 int t_stem_wgrad(camal_trainer* t, hipStream_t s, const TLayer& l, const float* dz, const float* x, float* grads, int B, int L) {
     const int nseg = stem_nseg(L);
     hipLaunchKernelGGL(stem_wgrad_kernel, dim3(B, nseg), dim3(256), 0, s, dz, x, t->stem_part, L, l.ks);
-    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(l.ks), dim3(256), 0, s, t->stem_part, B * nseg, l.ks, grads + l.w);
-    hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(128), 0, s, grads + l.b, (size_t)l.cout, 0.f);
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(l.ks), dim3(256), 0, s, t->stem_part, B * nseg, l.ks, grads + l.w,
+                       grads + l.b);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -221,7 +228,6 @@ int t_stem_wgrad(camal_trainer* t, hipStream_t s, const TLayer& l, const float* 
 // = adjoint conv with zero padding on the extended range, then fold of the replicate padding.
 int t_dgrad(camal_trainer* t, hipStream_t s, const TLayer& l, const float* params, float* wflip, const float* dz,
             float* dx, int B, int L) {
-    if (int r = t_pack(s, params + l.w, wflip, /*cout'=*/l.cin, /*cin'=*/l.cout, l.ks, 1)) return r;
     const int pad = l.ks >> 1, Lp = L + 2 * pad;
     int r;
     if (l.cin == C1 && l.cout == C1) r = t_conv<C1, C1, false>(t, s, wflip, t->zeros, l.ks, dz, nullptr, t->gXP, B, Lp, L, 2 * pad, t->zeros);
@@ -321,6 +327,7 @@ int camal_train_fwd_bwd(camal_trainer* t, const float* params, float* running, c
     const int N = B * L;
     int r;
 
+    if ((r = t_pack_all(t, s, params, grads != nullptr))) return r;
     // ------------------------------------ forward (train mode) ------------------------------------
     {   // block 1 stem: the two Cin = 1 convs on the VALU
         const TLayer& l0 = Y.conv[0];
@@ -341,7 +348,6 @@ int camal_train_fwd_bwd(camal_trainer* t, const float* params, float* running, c
             if ((r = t_bn_stats_any(t, s, t->z[l.zi], N, l, momentum, running))) return r;
             if (i == 0 && b == 1) {  // block 2 skip: BN(Conv1x1(block input))
                 const TLayer& lr = Y.res[1];
-                if ((r = t_pack(s, params + lr.w, t->wpack_res2, lr.cout, lr.cin, 1, 0))) return r;
                 if ((r = t_conv<C1, C2, false>(t, s, t->wpack_res2, params + lr.b, 1, in, nullptr, t->z[lr.zi], B, L, L, 0, nullptr))) return r;
                 if ((r = t_bn_stats_any(t, s, t->z[lr.zi], N, lr, momentum, running))) return r;
             }
@@ -396,7 +402,6 @@ int camal_train_fwd_bwd(camal_trainer* t, const float* params, float* running, c
             if ((r = t_dgrad(t, s, l, params, t->wflip[li], t->gZ, dnext, B, L))) return r;
             if (li == 3) {  // block 2 input also feeds the 1x1 skip: d(out1) += W_r^T dzr (accumulated in place)
                 const TLayer& lr = Y.res[1];
-                if ((r = t_pack(s, params + lr.w, t->wflip_res2, lr.cin, lr.cout, 1, 1))) return r;
                 if ((r = t_conv<C2, C1, true>(t, s, t->wflip_res2, t->zeros, 1, t->gZr, dnext, dnext, B, L, L, 0, t->zeros))) return r;
             }
             std::swap(da, dnext);

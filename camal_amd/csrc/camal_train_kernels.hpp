@@ -18,8 +18,23 @@ namespace camal {
 //   flip == 0 (forward):  W'[co' = 32 mt + i][ci' = 8 cp + 4 h + s][tap]        = w[co'][ci'][tap]
 //   flip == 1 (dgrad): the adjoint conv has Cout' = Cin, Cin' = Cout and a reversed kernel:
 //                         W'[co'][ci'][tap] = w[ci'][co'][ks - 1 - tap]
-__global__ void pack_w_kernel(const float* __restrict__ w, float* __restrict__ out, int coutp, int cinp, int ks,
-                              int flip) {
+// One launch packs every MFMA layer of a member in both orientations (blockIdx.y = job): 18 launches of a few
+// microseconds each were 2 % of the training step.
+struct PackJob {
+    const float* w;
+    float* out;
+    int coutp, cinp, ks, flip;
+};
+#define PACK_JOBS 18
+struct PackJobs {
+    PackJob j[PACK_JOBS];
+};
+
+__global__ void pack_w_kernel(PackJobs jobs) {
+    const PackJob& job = jobs.j[blockIdx.y];
+    const float* __restrict__ w = job.w;
+    float* __restrict__ out = job.out;
+    const int coutp = job.coutp, cinp = job.cinp, ks = job.ks, flip = job.flip;
     const int total = coutp * cinp * ks;
     const int ncp = cinp / 8;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
@@ -445,16 +460,35 @@ __global__ __launch_bounds__(COUT * 2) void wgrad_kernel(const float* __restrict
         }
 }
 
-// grad[co][ci][j] = sum_split part[split][j][co][ci]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int cout, int cin, int ks,
-                                    float* __restrict__ grad) {
+// grad[co][ci][j] = sum_split part[split][j][co][ci]; bias_grad[0..cout) = 0 (see t_wgrad).  Four ci per lane and
+// four lanes per quad, each walking every fourth split with independent 16-byte loads, combined in a fixed order:
+// one lane per element walking all splits moved the partials at 1.9 TB/s.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int cout, int cin,
+                                                           int ks, float* __restrict__ grad, float* __restrict__ bias_grad) {
+    __shared__ float4 red[4][64];
     const int total = cout * cin * ks;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const int ci = idx % cin, co = (idx / cin) % cout, j = idx / (cin * cout);
-        float a = 0.f;
-        for (int s = 0; s < nsplit; ++s) a += part[(size_t)s * total + idx];
-        grad[((size_t)co * cin + ci) * ks + j] = a;
+    const int q = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int idx = (blockIdx.x * 64 + q) * 4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (idx < total) {
+#pragma unroll 8
+        for (int s = g; s < nsplit; s += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(part + (size_t)s * total + idx);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
     }
+    red[g][q] = a;
+    __syncthreads();
+    if (g == 0 && idx < total) {
+        const float4 b = red[1][q], c = red[2][q], d = red[3][q];
+        const int ci = idx % cin, co = (idx / cin) % cout, j = idx / (cin * cout);
+        float* o = grad + ((size_t)co * cin + ci) * ks + j;
+        o[0] = (a.x + b.x) + (c.x + d.x);
+        o[ks] = (a.y + b.y) + (c.y + d.y);
+        o[2 * ks] = (a.z + b.z) + (c.z + d.z);
+        o[3 * ks] = (a.w + b.w) + (c.w + d.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < cout) bias_grad[threadIdx.x] = 0.f;
 }
 
 // Cin = 1 layers: part[b * nseg + seg][j][co] = sum over the segment's t of dz[b][t][co] * x[b][clamp(t + j - pad)]
@@ -502,7 +536,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 // grad[co][j] = sum_p part[p][j][co], one workgroup per tap: four lanes per channel walk every fourth partial
 // (independent loads), combined in a fixed order
 __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ part, int nparts, int ks,
-                                                                float* __restrict__ grad) {
+                                                                float* __restrict__ grad, float* __restrict__ bias_grad) {
     __shared__ float red[4][64];
     const int j = blockIdx.x, co = threadIdx.x & 63, g = threadIdx.x >> 6;
     float a = 0.f;
@@ -511,6 +545,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __r
     red[g][co] = a;
     __syncthreads();
     if (g == 0) grad[co * ks + j] = (red[0][co] + red[1][co]) + (red[2][co] + red[3][co]);
+    if (g == 1 && j == 0) bias_grad[co] = 0.f;
 }
 
 // ---- AdamW (torch.optim.AdamW defaults: torch_trainer.py:35; decoupled weight decay) -------------------
@@ -527,10 +562,6 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
         const float denom = sqrtf(vi) / bias_c2_sqrt + eps;
         p[i] = pi - (lr / bias_c1) * (mi / denom);
     }
-}
-
-__global__ void fill_kernel(float* __restrict__ p, size_t n, float v) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
 }  // namespace camal
