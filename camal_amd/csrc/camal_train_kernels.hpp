@@ -422,26 +422,54 @@ __global__ __launch_bounds__(COUT * 2) void wgrad_kernel(const float* __restrict
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[j][k] = 0.f;
 
+    // The next tile's rows travel from global memory into registers while this tile's MFMAs run (one LDS copy of
+    // each tile: the waves of the CU's other workgroup cover the short register -> LDS phase).
+    constexpr int NTH = COUT * 2;
+    constexpr int DZ_PER = WG_TT * (COUT / 4) / NTH;                  // = 8 float4 of dz per lane
+    constexpr int A_Q = (WG_TT + NTAP - 1) * 8, A_PER = (A_Q + NTH - 1) / NTH;
+    static_assert(DZ_PER * NTH == WG_TT * (COUT / 4), "dz tile divides over the workgroup");
+    float4 rdz[DZ_PER], ra[A_PER];
+    auto fetch = [&](int b, int t0) {
+        // dz rows t0 .. t0+TT-1 (zeros past L), all COUT channels
+#pragma unroll
+        for (int u = 0; u < DZ_PER; ++u) {
+            const int q = threadIdx.x + u * NTH;
+            const int row = q / (COUT / 4), c4 = (q % (COUT / 4)) * 4;
+            const int t = t0 + row;
+            rdz[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < L) rdz[u] = *reinterpret_cast<const float4*>(dz + ((size_t)b * L + t) * COUT + c4);
+        }
+        // input rows t0 + j0 - pad .. (+ TT + ntap - 2), clamped = replicate padding, 32 channels
+#pragma unroll
+        for (int u = 0; u < A_PER; ++u) {
+            const int q = threadIdx.x + u * NTH;
+            if (q < A_Q) {
+                int p = t0 + j0 - pad + (q >> 3);
+                p = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
+                ra[u] = *reinterpret_cast<const float4*>(ain + ((size_t)b * L + p) * CIN + ci0 + (q & 7) * 4);
+            }
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int u = 0; u < DZ_PER; ++u) {
+            const int q = threadIdx.x + u * NTH;
+            *reinterpret_cast<float4*>(&s_dz[q / (COUT / 4)][(q % (COUT / 4)) * 4]) = rdz[u];
+        }
+#pragma unroll
+        for (int u = 0; u < A_PER; ++u) {
+            const int q = threadIdx.x + u * NTH;
+            if (q < A_Q) *reinterpret_cast<float4*>(&s_a[q >> 3][(q & 7) * 4]) = ra[u];
+        }
+    };
+    if (b0 < b1) fetch(b0, 0);
     for (int b = b0; b < b1; ++b) {
         for (int t0 = 0; t0 < L; t0 += WG_TT) {
             __syncthreads();
-            // dz rows t0 .. t0+TT-1 (zeros past L), all COUT channels
-            for (int q = threadIdx.x; q < WG_TT * (COUT / 4); q += COUT * 2) {
-                const int row = q / (COUT / 4), c4 = (q % (COUT / 4)) * 4;
-                const int t = t0 + row;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (t < L) v = *reinterpret_cast<const float4*>(dz + ((size_t)b * L + t) * COUT + c4);
-                *reinterpret_cast<float4*>(&s_dz[row][c4]) = v;
-            }
-            // input rows t0 + j0 - pad .. (+ TT + ntap - 2), clamped = replicate padding, 32 channels
-            for (int q = threadIdx.x; q < (WG_TT + NTAP - 1) * 8; q += COUT * 2) {
-                const int row = q >> 3, c4 = (q & 7) * 4;
-                int p = t0 + j0 - pad + row;
-                p = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
-                *reinterpret_cast<float4*>(&s_a[row][c4]) =
-                    *reinterpret_cast<const float4*>(ain + ((size_t)b * L + p) * CIN + ci0 + c4);
-            }
+            stash();
             __syncthreads();
+            if (t0 + WG_TT < L) fetch(b, t0 + WG_TT);
+            else if (b + 1 < b1) fetch(b + 1, 0);
 #pragma unroll 4
             for (int s = 0; s < WG_TT / 2; ++s) {
                 const float av = s_dz[2 * s + h][32 * wave + i];
