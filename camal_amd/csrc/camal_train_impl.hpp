@@ -184,23 +184,24 @@ int t_wgrad(camal_trainer* t, hipStream_t s, const TLayer& l, const float* dz, c
     const int nsplit = wgrad_splits(t, l, B, &wps);
     const size_t need = (size_t)nsplit * l.ks * l.cout * l.cin;
     if (need > t->wg_part_floats) return fail(CAMAL_ERR_STATE, "wgrad partial buffer too small");
-    // whole groups of WG_TAPS taps, then one launch for the remaining (odd) 1, 3, 5 or 7
+    // ceil(ks / WG_TAPS) tap groups of nearly equal size (9 = 5 + 4, 25 = 7 + 6 + 6 + 6): a 1-tap remainder group
+    // staged a whole dz tile per 32 MFMAs
     auto launch = [&](auto cin_c, auto cout_c) {
         constexpr int CI = decltype(cin_c)::value, CO = decltype(cout_c)::value;
-        const int full = l.ks / WG_TAPS, rem = l.ks % WG_TAPS;
-        if (full)
-            hipLaunchKernelGGL((wgrad_kernel<CI, CO, WG_TAPS>), dim3(CI / 32, full, nsplit), dim3(CO * 2), 0, s, dz, ain,
-                               t->wg_part, B, L, l.ks, wps, 0);
-        const dim3 g(CI / 32, 1, nsplit);
-        const int tb = full * WG_TAPS;
-        switch (rem) {
-            case 0: break;
-            case 1: hipLaunchKernelGGL((wgrad_kernel<CI, CO, 1>), g, dim3(CO * 2), 0, s, dz, ain, t->wg_part, B, L, l.ks, wps, tb); break;
-            case 3: hipLaunchKernelGGL((wgrad_kernel<CI, CO, 3>), g, dim3(CO * 2), 0, s, dz, ain, t->wg_part, B, L, l.ks, wps, tb); break;
-            case 5: hipLaunchKernelGGL((wgrad_kernel<CI, CO, 5>), g, dim3(CO * 2), 0, s, dz, ain, t->wg_part, B, L, l.ks, wps, tb); break;
-            case 7: hipLaunchKernelGGL((wgrad_kernel<CI, CO, 7>), g, dim3(CO * 2), 0, s, dz, ain, t->wg_part, B, L, l.ks, wps, tb); break;
-            default: return fail(CAMAL_ERR_ARG, "kernel sizes are odd");
-        }
+        const int ng = (l.ks + WG_TAPS - 1) / WG_TAPS, base = l.ks / ng, rem = l.ks % ng;
+        auto go = [&](int ntap, int groups, int tap_base) {
+            if (!groups) return;
+            const dim3 g(CI / 32, groups, nsplit), blk(CO * 2);
+            switch (ntap) {
+#define CAMAL_WG_CASE(NT) \
+    case NT: hipLaunchKernelGGL((wgrad_kernel<CI, CO, NT>), g, blk, 0, s, dz, ain, t->wg_part, B, L, l.ks, wps, tap_base); break;
+                CAMAL_WG_CASE(1) CAMAL_WG_CASE(2) CAMAL_WG_CASE(3) CAMAL_WG_CASE(4)
+                CAMAL_WG_CASE(5) CAMAL_WG_CASE(6) CAMAL_WG_CASE(7) CAMAL_WG_CASE(8)
+#undef CAMAL_WG_CASE
+            }
+        };
+        go(base + 1, rem, 0);
+        go(base, ng - rem, rem * (base + 1));
         return 0;
     };
     int rc;
