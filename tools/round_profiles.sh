@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=$1
 cd "$R"
 set -e
-for wl in resnet_fp32 ensemble_bf16 long_bf16; do
+for wl in resnet_fp32 ensemble_bf16 long_bf16 train_fp32; do
   bash tools/profile.sh $wl ${TAG}_$wl > /dev/null
 done
 for wl in resnet_fp32 ensemble_bf16; do
