@@ -4,7 +4,7 @@ Public surface mirrors the reference (adrienpetralia/CamAL):
     from camal_amd import CamAL, CamALResNet, CAM
 Everything heavy is imported lazily so that ``import camal_amd`` works without a GPU.
 """
-__all__ = ["CamAL", "CamALResNet", "CAM", "Ensemble", "NILMmetrics", "Classifmetrics"]
+__all__ = ["CamAL", "CamALResNet", "ResNet", "CAM", "Ensemble", "NILMmetrics", "Classifmetrics"]
 
 
 def __getattr__(name):
@@ -14,6 +14,9 @@ def __getattr__(name):
     if name == "CamALResNet":
         from .resnet import CamALResNet
         return CamALResNet
+    if name == "ResNet":
+        from .resnet import ResNet
+        return ResNet
     if name == "CAM":
         from .cam import CAM
         return CAM

@@ -11,6 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CAMAL_HIP_LIB") or os.path.join(_HERE, "libcamal_hip.so")  # override: A/B builds
 
+ARCH_CAMAL, ARCH_RESNET = 0, 1
 FP32, BF16 = 0, 1
 PROF_CLASSES = ("stem", "conv", "conv_cam_head", "post", "other")
 
@@ -29,6 +30,8 @@ SIGNATURES = {
     "camal_last_error": (C.c_char_p, []),
     "camal_member_blob_floats": (_sz, [_i]),
     "camal_create": (_i, [_i, _i, C.POINTER(_i), _i, C.POINTER(_vp)]),
+    "camal_create_arch": (_i, [_i, _i, C.POINTER(_i), _i, _i, C.POINTER(_vp)]),
+    "camal_member_blob_floats_arch": (_sz, [_i, _i]),
     "camal_destroy": (_i, [_vp]),
     "camal_set_member_weights": (_i, [_vp, _i, C.POINTER(C.c_float), _sz]),
     "camal_set_chunk_windows": (_i, [_vp, _i]),

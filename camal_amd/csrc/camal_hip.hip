@@ -35,10 +35,18 @@ struct ConvShape { int cin, cout, k; };
 const ConvShape kConvs[9] = {{1, C1, -1},  {C1, C1, 7},  {C1, C1, 3},  {C1, C2, -1}, {C2, C2, 7},
                              {C2, C2, 3},  {C2, C2, -1}, {C2, C2, 7},  {C2, C2, 3}};
 
-size_t blob_floats(int k) {
+// Kernel size of ConvBlock i.  CAMAL_ARCH_CAMAL: (k, 7, 3) per block, replicate padding (camal_resnet.py:31,83);
+// CAMAL_ARCH_RESNET: (7, 5, 3) per block, zero "same" padding (classifiers/resnet.py:31,62).
+int conv_ks(int arch, int i, int k) {
+    if (arch == CAMAL_ARCH_RESNET) return i % 3 == 0 ? 7 : (i % 3 == 1 ? 5 : 3);
+    return kConvs[i].k < 0 ? k : kConvs[i].k;
+}
+
+size_t blob_floats(int k, int arch = CAMAL_ARCH_CAMAL) {
     size_t n = 0;
-    for (const auto& c : kConvs) {
-        int kk = c.k < 0 ? k : c.k;
+    for (int i = 0; i < 9; ++i) {
+        const auto& c = kConvs[i];
+        int kk = conv_ks(arch, i, k);
         n += (size_t)c.cout * c.cin * kk + c.cout;
     }
     n += C1 * 1 + C1;      // residual 1
@@ -90,6 +98,8 @@ struct camal_ctx {
     int post_windows = 4096;  // windows per post-processing launch (their CAM rows wait in the workspace)
     int num_cu = 256;
     size_t lds_per_cu = 160 * 1024;
+    int arch = CAMAL_ARCH_CAMAL;
+    float* zero_row = nullptr;  // 512 B of zeros: what a zero-padded layer reads outside the window
     int fused = 1;  // blocks 2 and 3 as fused-block kernels (block_kernel); 0: one conv_kernel per layer
     int fused_block1 = 1;  // with fused: block 1 as block1_kernel (env CAMAL_FUSED_BLOCK1=0: stem + two conv_kernels)
     std::vector<Member> m;
@@ -205,6 +215,7 @@ int block_nwc(size_t lds_per_cu, int k) {
 
 // can this member's blocks 2/3 run fused (LDS budget depends on the first kernel size)?
 bool fused_fits(const camal_ctx* c, int k) {
+    if (c->arch != CAMAL_ARCH_CAMAL) return false;  // the fused kernels are built for (k, 7, 3) with replicate padding
     if (c->precision == CAMAL_FP32)
         return block_nwc<float, C2, false, true>(c->lds_per_cu, k) && block_nwc<float, C1, true, false>(c->lds_per_cu, k);
     return block_nwc<__bf16, C2, false, true>(c->lds_per_cu, k) && block_nwc<__bf16, C1, true, false>(c->lds_per_cu, k);
@@ -335,7 +346,8 @@ int launch_conv(camal_ctx* c, hipStream_t s, const Layer& ly, const void* in, co
                 const float* wfc, float* cam, float* part, int BC, int L, float* cmax = nullptr) {
     return launch_conv_ex<DT, CIN, COUT, RELU, HAS_RES, HEAD>(c, c->num_cu, c->lds_per_cu, c->cam_row, s, ly.wpack,
                                                               ly.bias, ly.ks, in, res, out, wfc, cam, part, BC, L, L,
-                                                              ly.ks >> 1, nullptr, cmax);
+                                                              ly.ks >> 1, c->arch == CAMAL_ARCH_RESNET ? c->zero_row : nullptr,
+                                                              cmax);
 }
 
 template <typename DT, int CIN, int NWC, bool HAS_RES, bool HEAD>
@@ -426,7 +438,7 @@ int run_member(camal_ctx* c, hipStream_t s, const Member& m, const float* x, int
         {
             ProfScope ps(c, s, 0);
             hipLaunchKernelGGL(stem_kernel<DT>, dim3((L + 63) / 64, BC), dim3(256), 0, s, x, m.stem_w, m.stem_b, m.res1_w,
-                               m.res1_b, (DT*)w.a1, (DT*)w.r1, L, m.k);
+                               m.res1_b, (DT*)w.a1, (DT*)w.r1, L, m.k, c->arch == CAMAL_ARCH_RESNET);
             HIP_TRY(hipGetLastError());
         }
         // block 1: ConvBlock(7), ConvBlock(3) + residual (camal_resnet.py:35-38,56-58)
@@ -527,9 +539,20 @@ extern "C" {
 const char* camal_version(void) { return "camal_hip 1 gfx950"; }
 const char* camal_last_error(void) { return g_err.c_str(); }
 size_t camal_member_blob_floats(int kernel_size) { return blob_floats(kernel_size); }
+size_t camal_member_blob_floats_arch(int kernel_size, int arch) {
+    return arch == CAMAL_ARCH_CAMAL || arch == CAMAL_ARCH_RESNET ? blob_floats(kernel_size, arch) : 0;
+}
 
 int camal_create(int device_id, int n_members, const int* kernel_sizes, int precision, camal_ctx** out) {
+    return camal_create_arch(device_id, n_members, kernel_sizes, precision, CAMAL_ARCH_CAMAL, out);
+}
+
+int camal_create_arch(int device_id, int n_members, const int* kernel_sizes, int precision, int arch, camal_ctx** out) {
     if (!out || !kernel_sizes) return fail(CAMAL_ERR_ARG, "null argument");
+    if (arch != CAMAL_ARCH_CAMAL && arch != CAMAL_ARCH_RESNET) return fail(CAMAL_ERR_ARG, "arch must be 0 (CamALResNet) or 1 (ResNet)");
+    if (arch == CAMAL_ARCH_RESNET)
+        for (int e = 0; e < n_members; ++e)
+            if (kernel_sizes[e] != 7) return fail(CAMAL_ERR_ARG, "the ResNet variant has kernel sizes 7, 5, 3: pass 7");
     if (n_members < 1 || n_members > CAMAL_MAX_MEMBERS) return fail(CAMAL_ERR_ARG, "n_members must be in 1..16");
     if (precision != CAMAL_FP32 && precision != CAMAL_BF16) return fail(CAMAL_ERR_ARG, "precision must be 0 (fp32) or 1 (bf16)");
     for (int e = 0; e < n_members; ++e)
@@ -540,7 +563,7 @@ int camal_create(int device_id, int n_members, const int* kernel_sizes, int prec
     if (device_id < 0 || device_id >= ndev) return fail(CAMAL_ERR_ARG, "no such device");
     HIP_TRY(hipSetDevice(device_id));
     camal_ctx* c = new camal_ctx();
-    c->device = device_id; c->E = n_members; c->precision = precision;
+    c->device = device_id; c->E = n_members; c->precision = precision; c->arch = arch;
     // fused blocks pay 8 halo columns per tile: a win where the per-layer path is bandwidth/latency
     // bound (bf16), a 6 % loss of MFMA work where it is already MFMA-bound (fp32, 128-column tiles)
     c->fused = precision == CAMAL_BF16;
@@ -551,6 +574,10 @@ int camal_create(int device_id, int n_members, const int* kernel_sizes, int prec
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
     c->m.resize(n_members);
     for (int e = 0; e < n_members; ++e) c->m[e].k = kernel_sizes[e];
+    if (dev_alloc(c, (void**)&c->zero_row, 512) || hipMemset(c->zero_row, 0, 512) != hipSuccess) {
+        camal_destroy(c);
+        return fail(CAMAL_ERR_HIP, "allocating the zero row failed");
+    }
     *out = c;
     return 0;
 }
@@ -583,13 +610,13 @@ int camal_set_member_weights(camal_ctx* c, int member, const float* f, size_t n_
     if (member < 0 || member >= c->E) return fail(CAMAL_ERR_ARG, "member index out of range");
     Member& m = c->m[member];
     if (m.loaded) return fail(CAMAL_ERR_STATE, "member weights already set (create a new context to replace them)");
-    if (n_floats != blob_floats(m.k))
-        return fail(CAMAL_ERR_ARG, "blob has " + std::to_string(n_floats) + " floats, expected " + std::to_string(blob_floats(m.k)));
+    if (n_floats != blob_floats(m.k, c->arch))
+        return fail(CAMAL_ERR_ARG, "blob has " + std::to_string(n_floats) + " floats, expected " + std::to_string(blob_floats(m.k, c->arch)));
     HIP_TRY(hipSetDevice(c->device));
     const float* p = f;
     int r;
     for (int i = 0; i < 9; ++i) {
-        const int cin = kConvs[i].cin, cout = kConvs[i].cout, ks = kConvs[i].k < 0 ? m.k : kConvs[i].k;
+        const int cin = kConvs[i].cin, cout = kConvs[i].cout, ks = conv_ks(c->arch, i, m.k);
         const float* w = p; p += (size_t)cout * cin * ks;
         const float* b = p; p += cout;
         if (i == 0) {  // stem: [64][1][k] -> [k][64]

@@ -126,14 +126,15 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
                                                    const float* __restrict__ wr,     // [64]
                                                    const float* __restrict__ br,     // [64]
                                                    DT* __restrict__ a1, DT* __restrict__ r1,  // [B][L][64]
-                                                   int L, int ks) {
+                                                   int L, int ks, bool zero_pad = false) {
     __shared__ float xs[64 + 64];
     const int b = blockIdx.y, t0 = blockIdx.x * 64, pad = ks >> 1;
     const float* xb = x + (size_t)b * L;
     for (int i = threadIdx.x; i < 64 + ks - 1; i += 256) {
-        int p = t0 - pad + i;
-        p = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
-        xs[i] = xb[p];
+        const int p = t0 - pad + i;
+        const int pc = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
+        // zero_pad: padding="same" of classifiers/resnet.py:62 (zeros) instead of the replicate mode
+        xs[i] = (zero_pad && pc != p) ? 0.f : xb[pc];
     }
     __syncthreads();
     const int cg = threadIdx.x & 15, tq = threadIdx.x >> 4;  // 16 channel groups x 16 time slots

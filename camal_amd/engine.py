@@ -27,7 +27,7 @@ def folded_blob(sd) -> np.ndarray:
             "the HIP inference path implements the widths CamAL.eval() instantiates "
             "(in_channels=1, mid_channels=64, nb_class=2; reference core.py:386-390)")
     parts = []
-    for prefix, _ci, _co, _k in weights.conv_layers(k):
+    for prefix, _ci, _co, _k in weights.conv_layers(k, arch=weights.arch_of(sd)):
         w, b = weights.fold_conv_bn(
             sd[prefix + ".layers.0.weight"], sd[prefix + ".layers.0.bias"],
             sd[prefix + ".layers.1.weight"], sd[prefix + ".layers.1.bias"],
@@ -63,14 +63,19 @@ class Ensemble:
         self.precision_name = precision
         sds = [weights.to_numpy_state_dict(sd) for sd in state_dicts]
         self.kernel_sizes = [weights.kernel_size_of(sd) for sd in sds]
+        archs = {weights.arch_of(sd) for sd in sds}
+        if len(archs) != 1:
+            raise ValueError("the members of one ensemble share one classifier architecture")
+        self.arch = archs.pop()
+        arch_id = {weights.ARCH_CAMAL: _lib.ARCH_CAMAL, weights.ARCH_RESNET: _lib.ARCH_RESNET}[self.arch]
         self.E = len(sds)
         ks = (C.c_int * self.E)(*self.kernel_sizes)
         h = C.c_void_p()
-        _lib.check(self.lib.camal_create(self.dev_index, self.E, ks, self.precision, C.byref(h)))
+        _lib.check(self.lib.camal_create_arch(self.dev_index, self.E, ks, self.precision, arch_id, C.byref(h)))
         self._h = h
         for e, sd in enumerate(sds):
             blob = folded_blob(sd)
-            assert blob.size == self.lib.camal_member_blob_floats(self.kernel_sizes[e])
+            assert blob.size == self.lib.camal_member_blob_floats_arch(self.kernel_sizes[e], arch_id)
             _lib.check(self.lib.camal_set_member_weights(
                 self._h, e, blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size))
         if chunk_windows:

@@ -36,6 +36,8 @@ class _LinearHandle:
 
 
 class CamALResNet:
+    _arch = weights.ARCH_CAMAL
+
     def __init__(self, kernel_size: int = 7, in_channels: int = 1, mid_channels: int = 64,
                  norm: str = "BatchNorm", nb_class: int = 2):
         if kernel_size % 2 != 1:
@@ -47,7 +49,8 @@ class CamALResNet:
         self._engine = None
         self._params = OrderedDict()
         # torch's default initialisers (Conv1d / Linear: U(-1/sqrt(fan_in), 1/sqrt(fan_in)); BN: 1, 0)
-        for key, (shape, dt) in weights.state_dict_spec(kernel_size, in_channels, mid_channels, nb_class).items():
+        spec = weights.state_dict_spec(kernel_size, in_channels, mid_channels, nb_class, self._arch)
+        for key, (shape, dt) in spec.items():
             if key.endswith("num_batches_tracked"):
                 v = np.array(0, np.int64)
             elif key.endswith("running_mean"):
@@ -58,7 +61,7 @@ class CamALResNet:
                 v = np.ones(shape, np.float32) if key.endswith("weight") else np.zeros(shape, np.float32)
             else:
                 wkey = key[:-4] + "weight" if key.endswith("bias") else key
-                wshape = weights.state_dict_spec(kernel_size, in_channels, mid_channels, nb_class)[wkey][0]
+                wshape = spec[wkey][0]
                 fan_in = int(np.prod(wshape[1:]))
                 bound = 1.0 / np.sqrt(fan_in)
                 v = torch.empty(shape).uniform_(-bound, bound).numpy().astype(np.float32)
@@ -76,7 +79,7 @@ class CamALResNet:
         missing = [k for k in self._params if k not in sd]
         unexpected = [k for k in sd if k not in self._params]
         if strict and (missing or unexpected):
-            raise RuntimeError(f"Error(s) in loading state_dict for CamALResNet: missing {missing}, unexpected {unexpected}")
+            raise RuntimeError(f"Error(s) in loading state_dict for {type(self).__name__}: missing {missing}, unexpected {unexpected}")
         for k in self._params:
             if k in sd:
                 v = np.asarray(sd[k])
@@ -87,8 +90,9 @@ class CamALResNet:
         return self
 
     def named_parameters(self):
-        for k in weights.trainable_keys(self.kernel_size, self.in_channels, self.mid_channels):
-            yield k, torch.from_numpy(self._params[k])
+        for k in self._params:
+            if not k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+                yield k, torch.from_numpy(self._params[k])
 
     def parameters(self):
         return [p for _, p in self.named_parameters()]
@@ -123,9 +127,24 @@ class CamALResNet:
     def forward(self, x):
         """x [B,1,L] (or [B,L]) -> logits [B,2] on the device (camal_resnet.py:21-23)."""
         if self.training:
+            if self._arch != weights.ARCH_CAMAL:
+                raise NotImplementedError("the HIP training step implements CamALResNet (what CamAL.train builds, "
+                                          "reference core.py:106); ResNet runs in eval() mode")
             from .trainer import forward_train
             return forward_train(self, x)
         logits, _ = self.engine().forward_cam(x, want_cam=False)
         return logits[0]
 
     __call__ = forward
+
+
+class ResNet(CamALResNet):
+    """Mirror of the reference's second classifier (``src/models/camal/classifiers/resnet.py:3-23``): the same three
+    ResNetBlocks, state-dict key names and head, with kernel sizes 7, 5, 3 in every block (:31) and zero ``"same"``
+    padding (:62) instead of the replicate mode.  Inference (``eval()``), CAM and the ensemble post-processing run
+    on it through the same entry points (``camal_create_arch(..., CAMAL_ARCH_RESNET)``)."""
+    _arch = weights.ARCH_RESNET
+
+    def __init__(self, in_channels: int = 1, mid_channels: int = 64, nb_class: int = 2):
+        super().__init__(kernel_size=7, in_channels=in_channels, mid_channels=mid_channels, nb_class=nb_class)
+        self.input_args = {"in_channels": in_channels, "nb_class": nb_class}  # resnet.py:8-11

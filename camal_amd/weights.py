@@ -13,6 +13,8 @@ from __future__ import annotations
 import numpy as np
 
 INNER_KERNELS = (None, 7, 3)  # camal_resnet.py:31 — only the first conv uses `kernel_size`
+RESNET_KERNELS = (7, 5, 3)    # classifiers/resnet.py:31 — the fixed-kernel variant (zero "same" padding, :62)
+ARCH_CAMAL, ARCH_RESNET = "camal", "resnet"
 
 
 def block_channels(in_channels=1, mid_channels=64):
@@ -20,13 +22,16 @@ def block_channels(in_channels=1, mid_channels=64):
     return [(in_channels, mid_channels), (mid_channels, 2 * mid_channels), (2 * mid_channels, 2 * mid_channels)]
 
 
-def conv_layers(kernel_size, in_channels=1, mid_channels=64):
+def conv_layers(kernel_size, in_channels=1, mid_channels=64, arch=ARCH_CAMAL):
     """Flat list of the 9 ConvBlocks as (key_prefix, Cin, Cout, k)."""
     out = []
     for b, (cin, cout) in enumerate(block_channels(in_channels, mid_channels)):
         chans = [cin, cout, cout, cout]
         for i in range(3):
-            k = kernel_size if i == 0 else INNER_KERNELS[i]
+            if arch == ARCH_RESNET:
+                k = RESNET_KERNELS[i]
+            else:
+                k = kernel_size if i == 0 else INNER_KERNELS[i]
             out.append((f"layers.{b}.layers.{i}", chans[i], chans[i + 1], k))
     return out
 
@@ -37,8 +42,9 @@ def residual_layers(in_channels=1, mid_channels=64):
             for b, (cin, cout) in enumerate(block_channels(in_channels, mid_channels)) if cin != cout]
 
 
-def state_dict_spec(kernel_size, in_channels=1, mid_channels=64, nb_class=2):
-    """Ordered {key: (shape, dtype)} exactly as ``CamALResNet.state_dict()`` yields it."""
+def state_dict_spec(kernel_size, in_channels=1, mid_channels=64, nb_class=2, arch=ARCH_CAMAL):
+    """Ordered {key: (shape, dtype)} exactly as ``CamALResNet.state_dict()`` yields it
+    (``arch="resnet"``: ``classifiers/resnet.py``'s ``ResNet``, same names, kernels 7/5/3)."""
     spec = {}
 
     def bn(prefix, c):
@@ -48,7 +54,7 @@ def state_dict_spec(kernel_size, in_channels=1, mid_channels=64, nb_class=2):
         spec[prefix + ".running_var"] = ((c,), np.float32)
         spec[prefix + ".num_batches_tracked"] = ((), np.int64)
 
-    convs = conv_layers(kernel_size, in_channels, mid_channels)
+    convs = conv_layers(kernel_size, in_channels, mid_channels, arch)
     res = {p: (ci, co) for p, ci, co in residual_layers(in_channels, mid_channels)}
     for b in range(3):
         for i in range(3):
@@ -79,7 +85,7 @@ def count_parameters(kernel_size, in_channels=1, mid_channels=64):
 
 
 def make_state_dict(kernel_size, seed=0, in_channels=1, mid_channels=64, nb_class=2,
-                    head_gain=1.0, head_bias=(0.0, 0.0), randomize_bn=True, head_aligned=True):
+                    head_gain=1.0, head_bias=(0.0, 0.0), randomize_bn=True, head_aligned=True, arch=ARCH_CAMAL):
     """Seeded NumPy state dict (He-scaled convs, randomised BN statistics).
 
     ``head_gain`` scales ``linear.weight`` and ``head_bias`` sets ``linear.bias`` — the
@@ -89,9 +95,9 @@ def make_state_dict(kernel_size, seed=0, in_channels=1, mid_channels=64, nb_clas
     CAM is non-negative and grows with the (post-ReLU) feature energy, i.e. members agree
     on high-power windows and CAM peaks sit on the pulses, like a trained detector.
     """
-    rng = np.random.default_rng([seed, kernel_size, in_channels, mid_channels])
+    rng = np.random.default_rng([seed, kernel_size, in_channels, mid_channels] + ([1] if arch == ARCH_RESNET else []))
     sd = {}
-    for key, (shape, dt) in state_dict_spec(kernel_size, in_channels, mid_channels, nb_class).items():
+    for key, (shape, dt) in state_dict_spec(kernel_size, in_channels, mid_channels, nb_class, arch).items():
         if key.endswith("num_batches_tracked"):
             sd[key] = np.array(100 if randomize_bn else 0, dtype=np.int64)
         elif key.endswith("running_mean"):
@@ -145,3 +151,14 @@ def to_numpy_state_dict(sd):
 
 def kernel_size_of(sd):
     return int(np.asarray(sd["layers.0.layers.0.layers.0.weight"]).shape[2])
+
+
+def arch_of(sd):
+    """Which classifier a state dict belongs to: the two share every key name; the second ConvBlock of a block has
+    kernel 7 in ``CamALResNet`` (camal_resnet.py:31) and 5 in ``ResNet`` (classifiers/resnet.py:31)."""
+    k2 = int(np.asarray(sd["layers.0.layers.1.layers.0.weight"]).shape[2])
+    if k2 == 7:
+        return ARCH_CAMAL
+    if k2 == 5 and kernel_size_of(sd) == 7:
+        return ARCH_RESNET
+    raise ValueError(f"state dict is neither CamALResNet's nor ResNet's (second kernel {k2})")

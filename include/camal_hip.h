@@ -38,6 +38,10 @@ extern "C" {
 #define CAMAL_FP32 0 /* fp32 activations, v_mfma_f32_32x32x2_f32 (exact fp32)            */
 #define CAMAL_BF16 1 /* bf16 activations/weights, v_mfma_f32_16x16x32_bf16, fp32 accumulate */
 
+/* Classifier architectures (same state-dict key names, widths 1 -> 64 -> 128 -> 128, same head and CAM):       */
+#define CAMAL_ARCH_CAMAL 0  /* CamALResNet, camal_resnet.py:4-89: kernels (k, 7, 3) per block, replicate padding   */
+#define CAMAL_ARCH_RESNET 1 /* ResNet, classifiers/resnet.py:3-68: kernels (7, 5, 3) per block, zero "same" padding */
+
 typedef struct camal_ctx camal_ctx;
 
 /* Version / build info of the library ("camal_hip <n> gfx950"). */
@@ -57,6 +61,13 @@ size_t camal_member_blob_floats(int kernel_size);
  * E ensemble members (kernel_sizes[E], each odd, 1..63) on `device_id`.                   */
 int camal_create(int device_id, int n_members, const int* kernel_sizes, int precision, camal_ctx** out);
 int camal_destroy(camal_ctx* ctx);
+
+/* camal_create for either classifier.  CAMAL_ARCH_RESNET replaces instantiating classifiers/resnet.py's ResNet
+ * (resnet.py:3-23; every kernel_sizes[e] must be 7, its first kernel): blob layout as above with k_i = 7,5,3,
+ * layers padded with zeros (resnet.py:58-62).  That architecture runs one kernel per ConvBlock in either precision
+ * (the fused-block kernels are built for CamALResNet's layer list).                                           */
+int camal_create_arch(int device_id, int n_members, const int* kernel_sizes, int precision, int arch, camal_ctx** out);
+size_t camal_member_blob_floats_arch(int kernel_size, int arch); /* 0 for an unknown arch */
 
 /* Upload one member's folded weights (HOST pointer, layout above); the library re-lays them
  * out into MFMA fragment order.  Replaces load_state_dict + .to(device) (core.py:391-398). */

@@ -50,6 +50,33 @@ def conv1d_replicate(x, w, b, dtype=np.float32):
     return out
 
 
+def conv1d_same_zero(x, w, b, dtype=np.float32):
+    """Conv1d(stride 1, padding="same") with zeros outside the window — classifiers/resnet.py:58-62
+    (the ``ResNet`` variant; k odd, so "same" = k//2 zeros on either side)."""
+    x = np.asarray(x, dtype=dtype)
+    k = np.asarray(w).shape[2]
+    xp = np.pad(x, ((0, 0), (0, 0), (k // 2, k // 2)))
+    w = np.asarray(w, dtype=dtype)
+    n, cin, lp = xp.shape
+    length = lp - (k - 1)
+    cout = w.shape[0]
+    idx = np.arange(length)[:, None] + np.arange(k)[None, :]
+    w2 = w.reshape(cout, cin * k).T
+    out = np.empty((n, cout, length), dtype=dtype)
+    for i in range(n):
+        cols = xp[i][:, idx].transpose(1, 0, 2).reshape(length, cin * k)
+        out[i] = (cols @ w2).T
+    if b is not None:
+        out += np.asarray(b, dtype=dtype)[None, :, None]
+    return out
+
+
+def is_resnet_variant(sd):
+    """The two classifiers share every state-dict key; the second ConvBlock of a block has kernel 7 in
+    CamALResNet (camal_resnet.py:31) and 5 in ResNet (classifiers/resnet.py:31)."""
+    return int(np.asarray(sd["layers.0.layers.1.layers.0.weight"]).shape[2]) == 5
+
+
 def conv1d_1x1(x, w, b, dtype=np.float32):
     """Conv1d(kernel_size=1), no padding — the residual branch, camal_resnet.py:52."""
     x = np.asarray(x, dtype=dtype)
@@ -68,8 +95,10 @@ def batchnorm_eval(z, gamma, beta, mean, var, dtype=np.float32):
 
 
 def _conv_block(sd, prefix, x, dtype):
-    """ConvBlock = replicate-pad conv -> BN -> ReLU — camal_resnet.py:81-89."""
-    z = conv1d_replicate(x, sd[prefix + ".layers.0.weight"], sd[prefix + ".layers.0.bias"], dtype)
+    """ConvBlock = replicate-pad conv -> BN -> ReLU — camal_resnet.py:81-89
+    (ResNet variant: zero-pad conv -> BN -> ReLU, classifiers/resnet.py:53-68)."""
+    conv = conv1d_same_zero if is_resnet_variant(sd) else conv1d_replicate
+    z = conv(x, sd[prefix + ".layers.0.weight"], sd[prefix + ".layers.0.bias"], dtype)
     z = batchnorm_eval(
         z,
         sd[prefix + ".layers.1.weight"],

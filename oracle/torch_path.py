@@ -28,7 +28,10 @@ def _t(sd):
 def _conv_block(sd, p, x):
     w = sd[p + ".layers.0.weight"]
     k = w.shape[-1]
-    x = F.pad(x, (k // 2, k // 2), mode="replicate")  # padding_mode='replicate', camal_resnet.py:83
+    if oracle.is_resnet_variant(sd):
+        x = F.pad(x, (k // 2, k // 2))  # padding="same" (zeros), classifiers/resnet.py:62
+    else:
+        x = F.pad(x, (k // 2, k // 2), mode="replicate")  # padding_mode='replicate', camal_resnet.py:83
     z = F.conv1d(x, w, sd[p + ".layers.0.bias"])
     z = F.batch_norm(z, sd[p + ".layers.1.running_mean"], sd[p + ".layers.1.running_var"],
                      sd[p + ".layers.1.weight"], sd[p + ".layers.1.bias"], training=False, eps=1e-5)

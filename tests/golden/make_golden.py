@@ -246,13 +246,65 @@ def windows_case(name="windows_ref"):
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
 
 
+def resnet_variant_case(name, data, seeds, spread=2.0):
+    """classifiers/resnet.py's ``ResNet`` (kernels 7/5/3, zero "same" padding) member by member: forward logits and
+    ``CAM.run`` window by window (class_activation_map.py:34), on this repo's seeded weights.  ``CamAL.eval`` only
+    ever builds ``CamALResNet`` (core.py:386), so the reference has no ensemble path for this class to capture: the
+    ensemble body on top of these members is the one the ``ensemble_*`` fixtures pin."""
+    from src.models.camal.classifiers.resnet import ResNet
+    data32 = data.astype(np.float32)
+    n, length = data.shape
+    gains, biases, sds = [], [], []
+    for seed in seeds:
+        sd = weights.make_state_dict(7, seed=seed, arch=weights.ARCH_RESNET)
+        m = ResNet()
+        m.load_state_dict(to_torch_sd(sd))
+        m.eval()
+        with torch.no_grad():
+            lg = m(torch.from_numpy(data32[:, None, :])).numpy()
+        d = (lg[:, 1] - lg[:, 0]).astype(np.float64)
+        g = float(np.float32(spread / max(d.std(), 1e-6)))
+        b = (0.0, float(np.float32(-g * np.median(d))))
+        gains.append(g)
+        biases.append(b)
+        sds.append(weights.make_state_dict(7, seed=seed, arch=weights.ARCH_RESNET, head_gain=g, head_bias=b))
+    cams = np.zeros((len(seeds), n, length), np.float32)
+    labels = np.zeros((len(seeds), n), np.int32)
+    probs = np.zeros((len(seeds), n, 2), np.float32)
+    logits = np.zeros((len(seeds), n, 2), np.float32)
+    for e, sd in enumerate(sds):
+        m = ResNet()
+        m.load_state_dict(to_torch_sd(sd))
+        m.eval()
+        cam = CAM(model=m, device="cpu", last_conv_layer=m._modules["layers"][2], fc_layer_name=m._modules["linear"])
+        for i in range(n):
+            c, lab, p = cam.run(instance=data[i], returned_cam_for_label=1)
+            cams[e, i], labels[e, i], probs[e, i] = c, lab, p
+        with torch.no_grad():
+            logits[e] = m(torch.from_numpy(data32[:, None, :])).numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), seeds=np.array(seeds), head_gain=np.array(gains, np.float64),
+                        head_bias=np.array(biases, np.float64), data=data, cams=cams, labels=labels, probs=probs,
+                        logits=logits)
+    print(f"{name}: N={n} L={length} seeds={seeds} labels1={labels.mean():.2f} "
+          f"p1 in [{probs[..., 1].min():.3f},{probs[..., 1].max():.3f}]")
+
+
+def resnet_variant_cases():
+    resnet_variant_case("resnetvar_l192", synth.ukdale_windows(8, 192, seed=21), seeds=[301, 302])
+    # shorter than the 7-tap kernel's reach and not a tile multiple: every position touches the zero padding
+    resnet_variant_case("resnetvar_l5", synth.ukdale_windows(3, 5, seed=22), seeds=[303])
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "resnetvar":
+        return resnet_variant_cases()
     if len(sys.argv) > 1 and sys.argv[1] == "metrics":
         return metrics_case()
     if len(sys.argv) > 1 and sys.argv[1] == "windows":
         return windows_case()
     windows_case()
     metrics_case()
+    resnet_variant_cases()
     train_case("train_k7_l96", k=7, seed=201, n=48, length=96, batch=16, epochs=2)
     train_case("train_k25_l70", k=25, seed=202, n=24, length=70, batch=12, epochs=1)
     # 1. the BASELINE config-1 shape, shrunk: full ensemble, float32 data

@@ -29,6 +29,12 @@ def case_state_dicts(case):
             for k, g, b in zip(case["members"], case["head_gain"], case["head_bias"])]
 
 
+def resnetvar_state_dicts(case):
+    """Members of a ``resnetvar_*`` fixture: classifiers/resnet.py's ResNet (kernels 7/5/3, zero padding)."""
+    return [weights.make_state_dict(7, seed=int(sd), arch=weights.ARCH_RESNET, head_gain=float(g), head_bias=tuple(b))
+            for sd, g, b in zip(case["seeds"], case["head_gain"], case["head_bias"])]
+
+
 def rel_err(a, b):
     """max|a-b| / max|b| per row (last axis), worst row — the 'relative' of north_star:
     element-wise relative error is meaningless at the zero crossings of a CAM."""

@@ -9,7 +9,8 @@ sits within bf16 noise of the 0.5 threshold; probabilities within 2e-2 absolute.
 import numpy as np
 import pytest
 
-from tests.helpers import REL_TOL_FP32, STATE_AGREE_MIN, case_state_dicts, golden_cases, load_case, rel_err
+from tests.helpers import (REL_TOL_FP32, STATE_AGREE_MIN, case_state_dicts, golden_cases, load_case, rel_err,
+                           resnetvar_state_dicts)
 
 pytestmark = pytest.mark.gpu
 
@@ -183,3 +184,58 @@ def test_fused_blocks_equal_per_layer_kernels(torch_cuda, precision, L):
         assert rel_err(ca, cb) < 3e-2
     a.close()
     b.close()
+
+
+# ---- classifiers/resnet.py's ResNet (kernels 7/5/3, zero "same" padding) through camal_create_arch -----------------
+@pytest.mark.parametrize("name", golden_cases("resnetvar_"))
+def test_resnet_variant_fp32_vs_reference(torch_cuda, name):
+    from camal_amd.engine import Ensemble
+    c = load_case(name)
+    ens = Ensemble(resnetvar_state_dicts(c), device="cuda:0", precision="fp32")
+    assert ens.arch == "resnet"
+    logits, cam = ens.forward_cam(c["data"].astype(np.float32))
+    logits, cam = logits.cpu().numpy(), cam.cpu().numpy()
+    for e in range(ens.E):
+        assert rel_err(cam[e], c["cams"][e]) < REL_TOL_FP32
+        assert rel_err(logits[e].T, c["logits"][e].T) < REL_TOL_FP32
+        assert np.abs(_softmax(logits[e]) - c["probs"][e]).max() < REL_TOL_FP32
+    ens.close()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("L", [5, 7, 64, 130, 777])  # L >= w_ma: np.convolve(..., "same") is longer than the row below it
+def test_resnet_variant_localize_vs_oracle(torch_cuda, precision, L):
+    """Ensemble body on two ResNet-variant members against the oracle (ragged lengths, both precisions)."""
+    from camal_amd import synth, weights
+    from camal_amd.engine import Ensemble
+    from oracle import camal_oracle as oracle
+    x = synth.ukdale_windows(6, L, seed=400 + L).astype(np.float32)
+    sds = [weights.make_state_dict(7, seed=s, arch=weights.ARCH_RESNET, head_gain=3.0) for s in (311, 312)]
+    ens = Ensemble(sds, device="cuda:0", precision=precision)
+    res = ens.localize(x, want_avg_cam=True, want_members=True)
+    states, prob, avg_cam, _ = oracle.camal_predict(sds, x, return_intermediate=True)
+    mcam = res["member_cam"].cpu().numpy()
+    for e, sd in enumerate(sds):
+        cams, _labels, _probs = oracle.cam_batch(sd, x, 1)
+        assert rel_err(mcam[e], cams) < (REL_TOL_FP32 if precision == "fp32" else 3e-2)
+    p = res["prob"].cpu().numpy()
+    assert np.abs(p - prob[:, 0]).max() < (REL_TOL_FP32 if precision == "fp32" else 2e-2)
+    if precision == "fp32":
+        safe = np.abs(prob[:, 0] - 0.5) > 2e-3
+        assert (res["state"].cpu().numpy()[safe] == states[safe]).mean() >= STATE_AGREE_MIN
+        assert np.abs(res["avg_cam"].cpu().numpy()[safe] - avg_cam[safe]).max() < REL_TOL_FP32
+    ens.close()
+
+
+def test_resnet_variant_mirror_class(torch_cuda):
+    from camal_amd import ResNet
+    c = load_case("resnetvar_l192")
+    m = ResNet()
+    m.to("cuda:0")
+    m.load_state_dict(resnetvar_state_dicts(c)[0])
+    m.eval()
+    lg = m(c["data"].astype(np.float32)[:, None, :]).cpu().numpy()
+    assert rel_err(lg.T, c["logits"][0].T) < REL_TOL_FP32
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m(c["data"].astype(np.float32)[:, None, :])

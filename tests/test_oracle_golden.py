@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import camal_oracle as oracle
-from tests.helpers import REL_TOL_FP32, case_state_dicts, golden_cases, load_case, rel_err
+from tests.helpers import REL_TOL_FP32, case_state_dicts, golden_cases, load_case, rel_err, resnetvar_state_dicts
 
 CASES = golden_cases("ensemble_") + golden_cases("pair_")
 
@@ -45,6 +45,30 @@ def test_predict_matches_reference(name):
     # the signed case must contain the reference's negative states
     if "signed" in name:
         assert (c["states"] < 0).any()
+
+
+@pytest.mark.parametrize("name", golden_cases("resnetvar_"))
+def test_resnet_variant_members_match_reference(name):
+    """classifiers/resnet.py's ResNet (kernels 7/5/3, zero "same" padding): NumPy and torch restatements against
+    the reference class's own logits and CAM.run rows."""
+    import torch
+    from oracle import torch_path
+    c = load_case(name)
+    for e, sd in enumerate(resnetvar_state_dicts(c)):
+        assert oracle.is_resnet_variant(sd)
+        cams, labels, probs = oracle.cam_batch(sd, c["data"], 1)
+        assert rel_err(cams, c["cams"][e]) < REL_TOL_FP32
+        assert np.abs(probs - c["probs"][e]).max() < REL_TOL_FP32
+        diff = labels != c["labels"][e]  # only where the probabilities tie to within rounding
+        assert np.all(np.abs(c["probs"][e][diff, 1] - 0.5) < 1e-4)
+        logits = oracle.resnet_forward(sd, c["data"][:, None, :])
+        assert rel_err(logits.T, c["logits"][e].T) < REL_TOL_FP32
+        cam0, lab0, p0 = torch_path.cam_run({k: torch.as_tensor(np.asarray(v)) for k, v in sd.items()}, c["data"][0])
+        assert rel_err(cam0[None], c["cams"][e][:1]) < REL_TOL_FP32 and np.abs(p0 - c["probs"][e][0]).max() < REL_TOL_FP32
+
+
+def test_resnet_variant_fixtures_present():
+    assert len(golden_cases("resnetvar_")) >= 2
 
 
 def test_loop_variant_equals_batched():
