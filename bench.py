@@ -258,7 +258,7 @@ def main():
             "kernel_ms_per_step": {k: v[1] / args.steps for k, v in prof.items()},
             "sanity": {"state_on_fraction": on_frac, "windows_voted_on": vote_frac},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only: the other ranks would idle at the barrier
             res["cpu_baseline"] = cpu_baseline(sds, x_host)
         print(json.dumps(res), flush=True)
     if dist is not None:
