@@ -94,6 +94,10 @@ class CamAL(object):
         # knobs that do not exist in the reference
         self.precision = "fp32"   # "bf16": bf16 MFMA convs with fp32 accumulation
         self.prefilter = False    # True: reference device!='cpu' gating (core.py:292-300)
+        # True under torch.distributed with world > 1: train() spreads the (kernel size, try) candidates over the
+        # ranks (they are independent, core.py:104-158), each trained whole on one GPU with no gradient exchange;
+        # the logs are gathered once at the end.  False: every rank trains every candidate data-parallel.
+        self.member_parallel = False
         self._ensemble = None
 
     # ------------------------------------------------------------------ train (core.py:47-189)
@@ -122,9 +126,17 @@ class CamAL(object):
         camal_logs = {"ensemble_training_logs": {}}
         start_training_time = time.time()
 
+        from . import parallel
+        rank, _, world = parallel.world_info()
+        spread = bool(self.member_parallel) and world > 1
+        local_results = {}
+
         idx_clf = 0
         for kernel_size in list_kernel_sizes:
             for nth_try in range(n_try_by_kernel):
+                if spread and parallel.member_owner(idx_clf, world) != rank:
+                    idx_clf += 1
+                    continue
                 resnet_inst = CamALResNet(kernel_size=kernel_size, **self.resnet_kwargs)
                 train_loader = TSLoader(X_train, y_train, batch_size=training_kwargs["batch_size"], shuffle=True)
                 valid_loader = TSLoader(X_valid, y_valid, batch_size=1, shuffle=False)
@@ -134,17 +146,23 @@ class CamAL(object):
                     learning_rate=training_kwargs["lr"], weight_decay=training_kwargs["weight_decay"],
                     patience_es=training_kwargs["patience_es"], patience_rlr=training_kwargs["patience_rlr"],
                     n_warmup_epochs=training_kwargs["n_warmup_epochs"], device=self.device,
-                    all_gpu=training_kwargs["all_gpu"])
+                    all_gpu=training_kwargs["all_gpu"], data_parallel=not spread)
                 clf_trainer.train(training_kwargs["epochs"])
                 clf_trainer.restore_best_weights()
                 loss_eval, _ = clf_trainer.evaluate(test_loader)
                 print(f"Trained predictor {idx_clf} with kernel size: {kernel_size} (nth_try {nth_try}) - loss: {loss_eval}.")
 
-                tmp_loss_results[f"Predictor_{idx_clf}"] = loss_eval
-                camal_logs["ensemble_training_logs"][f"Predictor_{idx_clf}"] = clf_trainer.log
-                camal_logs["ensemble_training_logs"][f"Predictor_{idx_clf}"]["kernel_size"] = kernel_size
-                camal_logs["ensemble_training_logs"][f"Predictor_{idx_clf}"]["nth_try"] = nth_try
+                clf_trainer.log["kernel_size"] = kernel_size
+                clf_trainer.log["nth_try"] = nth_try
+                local_results[f"Predictor_{idx_clf}"] = (loss_eval, clf_trainer.log)
                 idx_clf += 1
+
+        if spread:
+            local_results = parallel.merge_member_logs(local_results)
+        for i in range(idx_clf):  # the reference's insertion order, whichever rank trained the candidate
+            loss_eval, log = local_results[f"Predictor_{i}"]
+            tmp_loss_results[f"Predictor_{i}"] = loss_eval
+            camal_logs["ensemble_training_logs"][f"Predictor_{i}"] = log
 
         camal_logs["training_time"] = round((time.time() - start_training_time), 3)
 

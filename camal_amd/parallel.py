@@ -57,6 +57,30 @@ def gather_shards(parts, n, dist=None):
     return out
 
 
+def member_owner(idx: int, world: int) -> int:
+    """Rank that trains candidate ``idx`` (kernel size x try, in the reference's loop order core.py:104-105) when
+    the members are spread over the ranks: round robin, so 5 kernels on 8 GPUs take 5 ranks, on 2 GPUs 3 + 2."""
+    return idx % max(1, world)
+
+
+def merge_member_logs(local: dict, dist=None) -> dict:
+    """{candidate name: (test loss, training log)} of every rank, identical on every rank afterwards.  Control path
+    (object all-gather once per ``CamAL.train``): the members' training itself exchanges nothing."""
+    if dist is None:
+        import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return dict(local)
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, local)
+    merged = {}
+    for p in parts:
+        for k, v in p.items():
+            if k in merged:
+                raise RuntimeError(f"candidate {k} was trained on two ranks")
+            merged[k] = v
+    return merged
+
+
 def allreduce_mean_(flat: torch.Tensor, dist=None):
     """In-place mean over ranks of the flat gradient bucket (one collective per step)."""
     if dist is None:

@@ -197,8 +197,11 @@ class TrainEngine:
                                                     self.BN_MOMENTUM, None, _lib.ptr(logits), None, None, self._stream()))
         return logits
 
+    data_parallel = True  # False: this rank trains the member alone (members spread over ranks, CamAL.train)
+
     def optimizer_step(self, lr, weight_decay):
-        parallel.allreduce_mean_(self.grads)  # no-op unless torch.distributed is initialised
+        if self.data_parallel:
+            parallel.allreduce_mean_(self.grads)  # no-op unless torch.distributed is initialised
         self.step_count += 1
         with torch.cuda.device(self.device):
             _lib.check(self.lib.camal_adamw_step(_lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.m),
@@ -227,7 +230,8 @@ class BasedClassifTrainer(object):
     def __init__(self, model, train_loader, valid_loader=None, learning_rate=1e-3, weight_decay=1e-2,
                  criterion=None, patience_es=None, patience_rlr=None, device="cuda", all_gpu=False,
                  valid_criterion=None, n_warmup_epochs=0, f_metrics=Classifmetrics(), verbose=False,
-                 plotloss=False, save_fig=False, path_fig=None, save_checkpoint=False, path_checkpoint=None):
+                 plotloss=False, save_fig=False, path_fig=None, save_checkpoint=False, path_checkpoint=None,
+                 data_parallel=True):
         if criterion is not None or valid_criterion is not None:
             raise NotImplementedError("the HIP training step implements nn.CrossEntropyLoss() (the reference default)")
         self.model = model
@@ -252,6 +256,7 @@ class BasedClassifTrainer(object):
         self.model.to(self.device)
         length = train_loader.samples.shape[-1]
         self.engine = TrainEngine(self.model, self.device, train_loader.batch_size, length)
+        self.engine.data_parallel = data_parallel  # not in the reference: see CamAL.member_parallel
 
     # ------------------------------------------------------------- train (torch_trainer.py:92-171)
     def train(self, n_epochs=10):

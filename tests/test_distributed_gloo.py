@@ -71,3 +71,72 @@ def test_two_rank_sharded_predict_and_bucket_allreduce(tmp_path):
         got_states[s:e] = a[2:2 + k].reshape(e - s, 16)
         got_prob[s:e] = a[2 + k:].reshape(e - s, 1)
     assert np.array_equal(got_states, whole_states) and np.allclose(got_prob, whole_prob)
+
+
+# ---- members spread over ranks (CamAL.member_parallel; SURVEY §8 e/f4) ----------------------------------------
+def _train_worker(rank, world, port, tmp):
+    import json
+    import camal_amd.trainer as trainer_mod
+    from camal_amd.core import CamAL
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class FakeTrainer:
+        """Stands in for the GPU trainer: the orchestration around it is what runs here."""
+
+        def __init__(self, model, train_loader, valid_loader=None, **kw):
+            self.k, self.data_parallel, self.log = model.kernel_size, kw["data_parallel"], {}
+
+        def train(self, epochs):
+            self.log = {"best_model_state_dict": {"w": torch.full((3,), float(self.k))}, "trained_on_rank": rank,
+                        "data_parallel": self.data_parallel}
+
+        def restore_best_weights(self):
+            pass
+
+        def evaluate(self, loader):
+            return abs(self.k - 9) + 0.5, None  # best: 9, then 7, then 5 / 15 ...
+
+    try:
+        trainer_mod.BasedClassifTrainer = FakeTrainer
+        rng = np.random.default_rng(3)
+        X = rng.normal(size=(40, 32)).astype(np.float32)
+        y = (np.arange(40) % 2).astype(np.float32)
+        camal = CamAL(n_predictors=3, device="cuda")
+        camal.member_parallel = True
+        camal.eval = lambda: None  # materialising the ensemble needs the GPU
+        camal.train((X, y), (X[:4], y[:4]), (X[4:8], y[4:8]), list_kernel_sizes=[5, 7, 9, 15, 25], epochs=1)
+        logs = camal.camal_logs
+        summary = {
+            "ids": logs["camal_predictors_id"],
+            "members": {n: [l["kernel_size"], l["trained_on_rank"], l["data_parallel"], "best_model_state_dict" in l]
+                        for n, l in logs["ensemble_training_logs"].items()},
+            "w9": float(logs["ensemble_training_logs"]["Predictor_2"]["best_model_state_dict"]["w"][0]),
+        }
+        with open(os.path.join(tmp, f"train{rank}.json"), "w") as f:
+            json.dump(summary, f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_member_parallel_training_orchestration(tmp_path):
+    import json
+    world = 2
+    mp.spawn(_train_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = [json.load(open(tmp_path / f"train{r}.json")) for r in range(world)]
+    assert got[0] == got[1]  # every rank ends with the same logs
+    g = got[0]
+    assert g["ids"] == ["Predictor_2", "Predictor_1", "Predictor_0"]  # kernels 9, 7, 5 by test loss
+    assert list(g["members"]) == [f"Predictor_{i}" for i in range(5)]  # the reference's insertion order
+    for i, (name, (k, trained_on, dp, has_sd)) in enumerate(g["members"].items()):
+        assert k == [5, 7, 9, 15, 25][i]
+        assert trained_on == parallel.member_owner(i, world) and dp is False
+        assert has_sd == (name in g["ids"])  # the losers' snapshots are dropped (core.py:176-179)
+    assert g["w9"] == 9.0
+
+
+def test_member_owner_round_robin():
+    assert [parallel.member_owner(i, 8) for i in range(5)] == [0, 1, 2, 3, 4]
+    assert [parallel.member_owner(i, 2) for i in range(5)] == [0, 1, 0, 1, 0]
+    assert parallel.merge_member_logs({"a": 1}) == {"a": 1}  # no process group: identity
