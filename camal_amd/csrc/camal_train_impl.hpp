@@ -184,24 +184,20 @@ int t_wgrad(camal_trainer* t, hipStream_t s, const TLayer& l, const float* dz, c
     const int nsplit = wgrad_splits(t, l, B, &wps);
     const size_t need = (size_t)nsplit * l.ks * l.cout * l.cin;
     if (need > t->wg_part_floats) return fail(CAMAL_ERR_STATE, "wgrad partial buffer too small");
-    // ceil(ks / WG_TAPS) tap groups of nearly equal size (9 = 5 + 4, 25 = 7 + 6 + 6 + 6): a 1-tap remainder group
-    // staged a whole dz tile per 32 MFMAs
+    // ceil(ks / WG_TAPS) tap groups of nearly equal size (9 = 5 + 4, 25 = 7 + 6 + 6 + 6), all in one grid:
+    // the first n_hi groups take base + 1 taps, the others base
     auto launch = [&](auto cin_c, auto cout_c) {
         constexpr int CI = decltype(cin_c)::value, CO = decltype(cout_c)::value;
         const int ng = (l.ks + WG_TAPS - 1) / WG_TAPS, base = l.ks / ng, rem = l.ks % ng;
-        auto go = [&](int ntap, int groups, int tap_base) {
-            if (!groups) return;
-            const dim3 g(CI / 32, groups, nsplit), blk(CO * 2);
-            switch (ntap) {
+        const int nhi_taps = rem ? base + 1 : base, n_hi = rem ? rem : ng;
+        const dim3 g(CI / 32, ng, nsplit), blk(CO * 2);
+        switch (nhi_taps) {
 #define CAMAL_WG_CASE(NT) \
-    case NT: hipLaunchKernelGGL((wgrad_kernel<CI, CO, NT>), g, blk, 0, s, dz, ain, t->wg_part, B, L, l.ks, wps, tap_base); break;
-                CAMAL_WG_CASE(1) CAMAL_WG_CASE(2) CAMAL_WG_CASE(3) CAMAL_WG_CASE(4)
-                CAMAL_WG_CASE(5) CAMAL_WG_CASE(6) CAMAL_WG_CASE(7) CAMAL_WG_CASE(8)
+    case NT: hipLaunchKernelGGL((wgrad_kernel<CI, CO, NT>), g, blk, 0, s, dz, ain, t->wg_part, B, L, l.ks, wps, n_hi); break;
+            CAMAL_WG_CASE(1) CAMAL_WG_CASE(2) CAMAL_WG_CASE(3) CAMAL_WG_CASE(4)
+            CAMAL_WG_CASE(5) CAMAL_WG_CASE(6) CAMAL_WG_CASE(7) CAMAL_WG_CASE(8)
 #undef CAMAL_WG_CASE
-            }
-        };
-        go(base + 1, rem, 0);
-        go(base, ng - rem, rem * (base + 1));
+        }
         return 0;
     };
     int rc;

@@ -399,20 +399,15 @@ __global__ __launch_bounds__(256) void fold_edges_kernel(const float* __restrict
 #define WG_TAPS 8
 #define WG_TT 64
 
-// NTAP (taps of this launch's groups) is a template parameter: with a run-time count every MFMA sat behind its
-// own branch, LDS read and lgkmcnt(0) (the kernel ran at 0.32 of the fp32 peak); j0 = tap_base + blockIdx.y * NTAP.
+// NTAP (taps of this workgroup's group) is a template parameter: with a run-time count every MFMA sat behind its
+// own branch, LDS read and lgkmcnt(0) (the kernel ran at 0.32 of the fp32 peak).
 template <int CIN, int COUT, int NTAP>
-__global__ __launch_bounds__(COUT * 2) void wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ ain,
-                                                         float* __restrict__ part, int B, int L, int ks,
-                                                         int windows_per_split, int tap_base) {
-    constexpr int NW = COUT / 32;
-    __shared__ float s_dz[WG_TT][COUT];
-    __shared__ float s_a[WG_TT + 64][32];
+__device__ __forceinline__ void wgrad_body(float (*s_dz)[COUT], float (*s_a)[32], const float* __restrict__ dz,
+                                           const float* __restrict__ ain, float* __restrict__ part, int B, int L, int ks,
+                                           int windows_per_split, int j0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int ci0 = blockIdx.x * 32;
-    constexpr int ntap = NTAP;
-    const int j0 = tap_base + blockIdx.y * NTAP;
     const int split = blockIdx.z, pad = ks >> 1;
     const int b0 = split * windows_per_split, b1 = min(B, b0 + windows_per_split);
 
@@ -486,6 +481,26 @@ __global__ __launch_bounds__(COUT * 2) void wgrad_kernel(const float* __restrict
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) po[(size_t)((reg & 3) + 8 * (reg >> 2) + 4 * h) * CIN] = acc[j][reg];
         }
+}
+
+// One launch for all tap groups of a layer: groups blockIdx.y < n_hi take NHI taps, the others NHI - 1 (a launch per
+// group size kept two workgroups per CU; one grid keeps three resident: +0.5 % on the step).  PMC: the MFMA pipe is
+// 0.69 busy on a single 7- or 8-tap group (512 workgroups), 0.83 on k = 25's four groups.  Groups of at most 4 taps
+// to get there on every layer: 3-5 % slower, a dz tile staged per 4 x 32 MFMAs costs more than the occupancy gains.
+template <int CIN, int COUT, int NHI>
+__global__ __launch_bounds__(COUT * 2) void wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ ain,
+                                                         float* __restrict__ part, int B, int L, int ks,
+                                                         int windows_per_split, int n_hi) {
+    __shared__ float s_dz[WG_TT][COUT];
+    __shared__ float s_a[WG_TT + WG_TAPS][32];
+    const int y = blockIdx.y;
+    if (y < n_hi) {
+        wgrad_body<CIN, COUT, NHI>(s_dz, s_a, dz, ain, part, B, L, ks, windows_per_split, y * NHI);
+    } else {
+        if constexpr (NHI > 1)
+            wgrad_body<CIN, COUT, NHI - 1>(s_dz, s_a, dz, ain, part, B, L, ks, windows_per_split,
+                                           n_hi * NHI + (y - n_hi) * (NHI - 1));
+    }
 }
 
 // grad[co][ci][j] = sum_split part[split][j][co][ci]; bias_grad[0..cout) = 0 (see t_wgrad).  Four ci per lane and
