@@ -350,19 +350,34 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restric
                                                           int* __restrict__ ncorrect_out) {
     const int k = threadIdx.x >> 7, c = threadIdx.x & 127;
     float a = 0.f;
+#pragma unroll 8
     for (int b = 0; b < B; ++b) a = fmaf(dlogits[2 * b + k], pooled[(size_t)b * 128 + c], a);
     dwfc[k * 128 + c] = a;
-    if (threadIdx.x < 2) {
-        float d = 0.f;
-        for (int b = 0; b < B; ++b) d += dlogits[2 * b + threadIdx.x];
-        dbfc[threadIdx.x] = d;
-    }
-    if (threadIdx.x == 2) {
+    // bias gradient, loss and accuracy: wave 0, lane l takes windows l, l + 64, ..., then a fixed xor tree (one lane
+    // walking the batch alone was 40 us of dependent loads)
+    if (threadIdx.x < 64) {
+        float d0 = 0.f, d1 = 0.f;
         double s = 0.0;
         int n = 0;
-        for (int b = 0; b < B; ++b) { s += (double)loss[b]; n += correct[b]; }
-        *loss_out = (float)(s / B);
-        *ncorrect_out = n;
+        for (int b = threadIdx.x; b < B; b += 64) {
+            d0 += dlogits[2 * b];
+            d1 += dlogits[2 * b + 1];
+            s += (double)loss[b];
+            n += correct[b];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            d0 += __shfl_xor(d0, o, 64);
+            d1 += __shfl_xor(d1, o, 64);
+            s += __shfl_xor(s, o, 64);
+            n += __shfl_xor(n, o, 64);
+        }
+        if (threadIdx.x == 0) {
+            dbfc[0] = d0;
+            dbfc[1] = d1;
+            *loss_out = (float)(s / B);
+            *ncorrect_out = n;
+        }
     }
 }
 
