@@ -215,7 +215,6 @@ int block_nwc(size_t lds_per_cu, int k) {
 
 // can this member's blocks 2/3 run fused (LDS budget depends on the first kernel size)?
 bool fused_fits(const camal_ctx* c, int k) {
-    if (c->arch != CAMAL_ARCH_CAMAL) return false;  // the fused kernels are built for (k, 7, 3) with replicate padding
     if (c->precision == CAMAL_FP32)
         return block_nwc<float, C2, false, true>(c->lds_per_cu, k) && block_nwc<float, C1, true, false>(c->lds_per_cu, k);
     return block_nwc<__bf16, C2, false, true>(c->lds_per_cu, k) && block_nwc<__bf16, C1, true, false>(c->lds_per_cu, k);
@@ -350,12 +349,13 @@ int launch_conv(camal_ctx* c, hipStream_t s, const Layer& ly, const void* in, co
                                                               cmax);
 }
 
-template <typename DT, int CIN, int NWC, bool HAS_RES, bool HEAD>
+// VARIANT: classifiers/resnet.py's block (second kernel 5, zero padding) instead of CamALResNet's (7, replicate)
+template <typename DT, int CIN, int NWC, bool HAS_RES, bool HEAD, bool VARIANT = false>
 int launch_block_w(camal_ctx* c, hipStream_t s, const Layer& l1, const Layer& l2, const Layer& l3, const Layer* lr,
                    const void* in, void* out, const float* wfc, float* cam, float* part, int BC, int L, float* cmax) {
     constexpr int NTB = BlockNT<DT>::NT;
     using G = BGeom<DT, CIN, NWC>;
-    auto kern = block_kernel<DT, CIN, NTB, NWC, 1, HAS_RES, HEAD>;
+    auto kern = block_kernel<DT, CIN, NTB, NWC, 1, HAS_RES, HEAD, VARIANT ? 5 : 7, VARIANT>;
     const size_t lds = block_lds<DT, CIN, NWC, HAS_RES, HEAD>(l1.ks);
     static size_t attr_set = 0;
     if (lds > attr_set) {
@@ -369,6 +369,8 @@ int launch_block_w(camal_ctx* c, hipStream_t s, const Layer& l1, const Layer& l2
     a.b1 = l1.bias; a.b2 = l2.bias; a.b3 = l3.bias; a.br = lr ? lr->bias : nullptr;
     a.wfc = wfc; a.cam = cam; a.part = part; a.cmax = cmax;
     a.L = L; a.ks1 = l1.ks; a.cam_row = c->cam_row;
+    a.zero_row = c->zero_row;
+    if (l2.ks != (VARIANT ? 5 : 7) || l3.ks != 3) return fail(CAMAL_ERR_STATE, "fused block: unexpected layer kernel sizes");
     a.tiles_per_window = (L + G::T - 1) / G::T;
     const long long total = (long long)a.tiles_per_window * BC;
     if (total > 0x7fffffffLL) return fail(CAMAL_ERR_ARG, "too many tiles in one pass");
@@ -386,6 +388,8 @@ int launch_block(camal_ctx* c, hipStream_t s, const Layer& l1, const Layer& l2, 
                  const void* in, void* out, const float* wfc, float* cam, float* part, int BC, int L,
                  float* cmax = nullptr) {
     const int nwc = block_nwc<DT, CIN, HAS_RES, HEAD>(c->lds_per_cu, l1.ks);
+    if (nwc == 8 && c->arch == CAMAL_ARCH_RESNET)
+        return launch_block_w<DT, CIN, 8, HAS_RES, HEAD, true>(c, s, l1, l2, l3, lr, in, out, wfc, cam, part, BC, L, cmax);
     if (nwc == 8) return launch_block_w<DT, CIN, 8, HAS_RES, HEAD>(c, s, l1, l2, l3, lr, in, out, wfc, cam, part, BC, L, cmax);
     return fail(CAMAL_ERR_ARG, "kernel size too large for the fused block tile");
 }
@@ -431,7 +435,8 @@ int run_member(camal_ctx* c, hipStream_t s, const Member& m, const float* x, int
                float* cam, float* part, float* cmax) {
     int r;
     const bool fused = c->fused && fused_fits(c, m.k);
-    if (fused && c->fused_block1) {
+    // (block1_kernel is built for CamALResNet's replicate-padded (k, 7, 3): the ResNet variant runs block 1 per layer)
+    if (fused && c->fused_block1 && c->arch == CAMAL_ARCH_CAMAL) {
         // block 1 in one launch: x in, 64-channel block output out
         if ((r = launch_block1<DT>(c, s, m, x, w.a1, BC, L))) return r;
     } else {

@@ -720,13 +720,16 @@ __device__ __forceinline__ void store_act_lds(char* dst, int row0, const Frag<DT
 }
 
 // rows just outside the window take the edge row's values (replicate padding of THIS layer's output)
+// (zero: they take zeros instead, the zero "same" padding of classifiers/resnet.py:62)
 template <typename DT, int CH = 128>
-__device__ __forceinline__ void fix_edges(char* buf, int guard, int g, int c_first, int c_last, bool lo, bool hi, int lane) {
+__device__ __forceinline__ void fix_edges(char* buf, int guard, int g, int c_first, int c_last, bool lo, bool hi, int lane,
+                                          bool zero = false) {
     constexpr int RB = CH * (int)sizeof(DT), CPR = RB / 16;
     if (lane < CPR) {
         if (lo) {
             const int src = c_first + guard;
-            const uint4 v = *reinterpret_cast<const uint4*>(buf + src * RB + ((lane ^ swz<CPR>(src)) << 4));
+            uint4 v = *reinterpret_cast<const uint4*>(buf + src * RB + ((lane ^ swz<CPR>(src)) << 4));
+            if (zero) v = make_uint4(0u, 0u, 0u, 0u);
             for (int d = 1; d <= g; ++d) {
                 const int dst = src - d;
                 if (dst >= 0) *reinterpret_cast<uint4*>(buf + dst * RB + ((lane ^ swz<CPR>(dst)) << 4)) = v;
@@ -734,7 +737,8 @@ __device__ __forceinline__ void fix_edges(char* buf, int guard, int g, int c_fir
         }
         if (hi) {
             const int src = c_last + guard;
-            const uint4 v = *reinterpret_cast<const uint4*>(buf + src * RB + ((lane ^ swz<CPR>(src)) << 4));
+            uint4 v = *reinterpret_cast<const uint4*>(buf + src * RB + ((lane ^ swz<CPR>(src)) << 4));
+            if (zero) v = make_uint4(0u, 0u, 0u, 0u);
             for (int d = 1; d <= g; ++d) {
                 const int dst = src + d;
                 *reinterpret_cast<uint4*>(buf + dst * RB + ((lane ^ swz<CPR>(dst)) << 4)) = v;
@@ -766,6 +770,7 @@ struct BlockArgs {
     float* part;       // [B][tiles_per_window][2]
     float* cmax;       // [B] or null: running max of the clipped CAM row (atomic max per head tile)
     int L, ks1, cam_row, tiles_per_window, total_tiles;
+    const void* zero_row;  // ZPAD kernels: 512 B of zeros = what lies outside the window (classifiers/resnet.py:62)
 };
 
 template <typename DT, int CIN, int NT, int NWC, int MTW = 1>
@@ -788,7 +793,9 @@ struct BlockGeom {
     }
 };
 
-template <typename DT, int CIN, int NT, int NWC, int MTW, bool HAS_RES, bool HEAD>
+// KS2 / ZPAD: the second ConvBlock's kernel size and the padding mode are compile-time (7, replicate = CamALResNet;
+// 5, zeros = the ResNet variant): as run-time values they cost the block-2 kernel 1.5 %.
+template <typename DT, int CIN, int NT, int NWC, int MTW, bool HAS_RES, bool HEAD, int KS2 = 7, bool ZPAD = false>
 __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
     using G = BlockGeom<DT, CIN, NT, NWC, MTW>;
     constexpr int N = G::N, T = G::T, RBI = G::RBI, CPRI = RBI / 16;
@@ -820,9 +827,11 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
             for (int pc = 0; pc < pieces; ++pc) {
                 const int q = pc * 64 + lane;
                 const int row = q / CPRI, c = (q % CPRI) ^ swz<CPRI>(row);
-                int p = t0 - 4 - pad1 + row_shift + row;
-                p = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
-                glds16(inb + (size_t)p * RBI + c * 16, buf + pc * 1024);
+                const int p = t0 - 4 - pad1 + row_shift + row;
+                const int pcl = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
+                const char* src = inb + (size_t)pcl * RBI + c * 16;
+                if (ZPAD && pcl != p) src = reinterpret_cast<const char*>(a.zero_row) + c * 16;
+                glds16(src, buf + pc * 1024);
             }
         };
         int tile = blockIdx.x;
@@ -906,7 +915,9 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
     constexpr int NCPI = CIN / Elem<DT>::K_PER_PAIR, NCPA = 128 / Elem<DT>::K_PER_PAIR;
     // wave-uniform weight bases; mma_layer adds the lane
     const uint4* w1 = a.w1 + (size_t)mt0 * ks1 * NCPI * 64;
-    const uint4* w2 = a.w2 + (size_t)mt0 * 7 * NCPA * 64;
+    constexpr int ks2 = KS2, pad2 = KS2 >> 1;
+    constexpr bool zpad = ZPAD;
+    const uint4* w2 = a.w2 + (size_t)mt0 * ks2 * NCPA * 64;
     const uint4* w3 = a.w3 + (size_t)mt0 * 3 * NCPA * 64;
     auto start_acc = [&](F (&acc)[MTW][NT], int layer) {  // accumulators = the layer's bias
 #pragma unroll
@@ -923,30 +934,30 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
         const int c_first = 4 - t0, c_last = L - 1 - t0 + 4;  // columns of positions 0 and L-1
 
         F acc[MTW][NT];
-        // ---- ConvBlock(k): X(P) -> A1(Q), rows = column + 3
+        // ---- ConvBlock(k): X(P) -> A1(Q), rows = column + pad2 (3 for the 7-tap second layer)
         STAMP(0);
         start_acc(acc, 0);
         mma_layer<DT, CIN, NT, MTW>(P, colw, ks1, w1, acc);
         STAMP(1);
 #pragma unroll
-        for (int m = 0; m < MTW; ++m) store_act_lds<DT, NT>(Q, colw + 3, acc[m], mt0 + m, opaque(lane));
+        for (int m = 0; m < MTW; ++m) store_act_lds<DT, NT>(Q, colw + pad2, acc[m], mt0 + m, opaque(lane));
         STAMP(2);
         __syncthreads();  // B1
         if (lo || hi) {
-            if (wave == 0) fix_edges<DT>(Q, 3, 3, c_first, c_last, lo, hi, lane);
+            if (wave == 0) fix_edges<DT>(Q, pad2, pad2, c_first, c_last, lo, hi, lane, zpad);
             __syncthreads();
         }
         STAMP(3);
-        // ---- ConvBlock(7): A1(Q) -> A2(P), rows = column + 1
+        // ---- ConvBlock(7 | 5): A1(Q) -> A2(P), rows = column + 1
         start_acc(acc, 1);
-        mma_layer<DT, 128, NT, MTW>(Q, colw, 7, w2, acc);
+        mma_layer<DT, 128, NT, MTW>(Q, colw, ks2, w2, acc);
         STAMP(4);
 #pragma unroll
         for (int m = 0; m < MTW; ++m) store_act_lds<DT, NT>(P, colw + 1, acc[m], mt0 + m, opaque(lane));
         STAMP(5);
         __syncthreads();  // B2
         if (lo || hi) {
-            if (wave == 0) fix_edges<DT>(P, 1, 1, c_first, c_last, lo, hi, lane);
+            if (wave == 0) fix_edges<DT>(P, 1, 1, c_first, c_last, lo, hi, lane, zpad);
             __syncthreads();
         }
         STAMP(6);

@@ -202,16 +202,19 @@ def test_resnet_variant_fp32_vs_reference(torch_cuda, name):
     ens.close()
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-@pytest.mark.parametrize("L", [5, 7, 64, 130, 777])  # L >= w_ma: np.convolve(..., "same") is longer than the row below it
-def test_resnet_variant_localize_vs_oracle(torch_cuda, precision, L):
-    """Ensemble body on two ResNet-variant members against the oracle (ragged lengths, both precisions)."""
+@pytest.mark.parametrize("L", [5, 7, 64, 130, 249, 777])  # L >= w_ma: np.convolve(..., "same") is longer than the row below it
+def test_resnet_variant_localize_vs_oracle(torch_cuda, precision, L, fused):
+    """Ensemble body on two ResNet-variant members against the oracle (ragged lengths, both precisions; blocks 2 and 3
+    as one kernel per ConvBlock and as fused-block kernels with the 5-tap second layer and zero padding)."""
     from camal_amd import synth, weights
     from camal_amd.engine import Ensemble
     from oracle import camal_oracle as oracle
     x = synth.ukdale_windows(6, L, seed=400 + L).astype(np.float32)
     sds = [weights.make_state_dict(7, seed=s, arch=weights.ARCH_RESNET, head_gain=3.0) for s in (311, 312)]
     ens = Ensemble(sds, device="cuda:0", precision=precision)
+    ens.set_fused(fused)
     res = ens.localize(x, want_avg_cam=True, want_members=True)
     states, prob, avg_cam, _ = oracle.camal_predict(sds, x, return_intermediate=True)
     mcam = res["member_cam"].cpu().numpy()
