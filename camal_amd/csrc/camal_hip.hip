@@ -395,11 +395,12 @@ int launch_block(camal_ctx* c, hipStream_t s, const Layer& l1, const Layer& l2, 
 }
 
 // fused block 1: x [BC][L] -> block output [BC][L][64]
-template <typename DT, int NWC>
+template <typename DT, int NWC, bool VARIANT = false>
 int launch_block1_w(camal_ctx* c, hipStream_t s, const Member& m, const float* x, void* out, int BC, int L) {
     constexpr int NTB = sizeof(DT) == 2 ? 4 : 2;  // column tiles per wave
     using G = Block1Geom<DT, NTB, NWC>;
-    auto kern = block1_kernel<DT, NTB, NWC>;
+    auto kern = block1_kernel<DT, NTB, NWC, VARIANT ? 5 : 7, VARIANT>;
+    if (m.conv[0].ks != (VARIANT ? 5 : 7) || m.conv[1].ks != 3) return fail(CAMAL_ERR_STATE, "fused block 1: unexpected layer kernel sizes");
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
@@ -426,6 +427,7 @@ int launch_block1_w(camal_ctx* c, hipStream_t s, const Member& m, const float* x
 // runs under the other's MFMAs: measured, no difference.)
 template <typename DT>
 int launch_block1(camal_ctx* c, hipStream_t s, const Member& m, const float* x, void* out, int BC, int L) {
+    if (c->arch == CAMAL_ARCH_RESNET) return launch_block1_w<DT, 8, true>(c, s, m, x, out, BC, L);
     return launch_block1_w<DT, 8>(c, s, m, x, out, BC, L);
 }
 
@@ -435,8 +437,7 @@ int run_member(camal_ctx* c, hipStream_t s, const Member& m, const float* x, int
                float* cam, float* part, float* cmax) {
     int r;
     const bool fused = c->fused && fused_fits(c, m.k);
-    // (block1_kernel is built for CamALResNet's replicate-padded (k, 7, 3): the ResNet variant runs block 1 per layer)
-    if (fused && c->fused_block1 && c->arch == CAMAL_ARCH_CAMAL) {
+    if (fused && c->fused_block1) {
         // block 1 in one launch: x in, 64-channel block output out
         if ((r = launch_block1<DT>(c, s, m, x, w.a1, BC, L))) return r;
     } else {

@@ -1103,7 +1103,8 @@ struct Block1Geom {
 };
 
 // NWC = 8: one workgroup per CU, 512-column tiles (bf16).  NWC = 4: half the tile, two workgroups per CU.
-template <typename DT, int NT, int NWC>
+// KS2 / ZPAD as in block_kernel (5, zeros: classifiers/resnet.py's block).
+template <typename DT, int NT, int NWC, int KS2 = 7, bool ZPAD = false>
 __global__ __launch_bounds__(NWC * 64) void block1_kernel(Block1Args a, const float* __restrict__ stem_w /*[k][64]*/,
                                                      const float* __restrict__ stem_b, const float* __restrict__ res_w,
                                                      const float* __restrict__ res_b) {
@@ -1121,9 +1122,10 @@ __global__ __launch_bounds__(NWC * 64) void block1_kernel(Block1Args a, const fl
 
     auto load_x = [&](int tile, int i) {
         const int b = tile / tpw, t0 = (tile - b * tpw) * T;
-        int p = t0 - 4 - pad1 + i;
-        p = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
-        return a.x[(size_t)b * L + p];
+        const int p = t0 - 4 - pad1 + i;
+        const int pcl = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
+        const float v = a.x[(size_t)b * L + pcl];
+        return (ZPAD && pcl != p) ? 0.f : v;
     };
     float* cst = reinterpret_cast<float*>(lds + G::CST_OFF);
     if (threadIdx.x < 64) {  // visible after the barrier below
@@ -1146,7 +1148,8 @@ __global__ __launch_bounds__(NWC * 64) void block1_kernel(Block1Args a, const fl
     const int sh = wave & 1, scol = (wave >> 1) * 64 * SC + lane;
     const int mt = wave & 1, ng = wave >> 1;
     const int colw = ng * NT * 32;
-    const uint4* w2 = a.w2 + (size_t)mt * 7 * NCP * 64;
+    constexpr int pad2 = KS2 >> 1;
+    const uint4* w2 = a.w2 + (size_t)mt * KS2 * NCP * 64;
     const uint4* w3 = a.w3 + (size_t)mt * 3 * NCP * 64;
     const float* sw = stem_w + 32 * sh;
 
@@ -1188,7 +1191,7 @@ __global__ __launch_bounds__(NWC * 64) void block1_kernel(Block1Args a, const fl
             constexpr int CPR = G::RB / 16;
 #pragma unroll
             for (int u = 0; u < SC; ++u) {
-                const int row = scol + 64 * u + 3, s = swz<CPR>(row);
+                const int row = scol + 64 * u + pad2, s = swz<CPR>(row);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {  // 8 groups of 4 channels
                     const int boff = (32 * sh + 4 * q) * (int)sizeof(DT);
@@ -1201,19 +1204,19 @@ __global__ __launch_bounds__(NWC * 64) void block1_kernel(Block1Args a, const fl
         STAMP1(1);
         __syncthreads();
         if (lo || hi) {
-            if (wave == 0) fix_edges<DT, 64>(A1, 3, 3, c_first, c_last, lo, hi, lane);
+            if (wave == 0) fix_edges<DT, 64>(A1, pad2, pad2, c_first, c_last, lo, hi, lane, ZPAD);
             __syncthreads();
         }
         STAMP1(2);
         F acc[1][NT];
         // ---- ConvBlock(7): A1 -> A2, rows = column + 1   (accumulators start from the bias)
         init_acc_bias<DT, NT>(acc[0], cst, mt, lane);
-        mma_layer<DT, 64, NT, 1>(A1, colw, 7, w2, acc);
+        mma_layer<DT, 64, NT, 1>(A1, colw, KS2, w2, acc);
         STAMP1(3);
         store_act_lds<DT, NT, 64>(A2, colw + 1, acc[0], mt, opaque(lane));
         __syncthreads();
         if (lo || hi) {
-            if (wave == 0) fix_edges<DT, 64>(A2, 1, 1, c_first, c_last, lo, hi, lane);
+            if (wave == 0) fix_edges<DT, 64>(A2, 1, 1, c_first, c_last, lo, hi, lane, ZPAD);
             __syncthreads();
         }
         // ---- ConvBlock(3): A2 -> registers; out = relu(. + b3) + (wr x + br)   (skip added after the ReLU)

@@ -64,8 +64,7 @@ int camal_destroy(camal_ctx* ctx);
 
 /* camal_create for either classifier.  CAMAL_ARCH_RESNET replaces instantiating classifiers/resnet.py's ResNet
  * (resnet.py:3-23; every kernel_sizes[e] must be 7, its first kernel): blob layout as above with k_i = 7,5,3,
- * layers padded with zeros (resnet.py:58-62).  Block 1 of that architecture runs one kernel per ConvBlock; blocks 2
- * and 3 follow camal_set_fused like CamALResNet's.                                                             */
+ * layers padded with zeros (resnet.py:58-62).  camal_set_fused applies to it like to CamALResNet.             */
 int camal_create_arch(int device_id, int n_members, const int* kernel_sizes, int precision, int arch, camal_ctx** out);
 size_t camal_member_blob_floats_arch(int kernel_size, int arch); /* 0 for an unknown arch */
 
