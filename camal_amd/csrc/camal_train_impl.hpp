@@ -21,7 +21,7 @@ struct TLayout {
     size_t wfc = 0, bfc = 0, n_params = 0, n_running = 0;
 };
 
-TLayout make_layout(int k) {
+TLayout make_layout(int k, int arch = CAMAL_ARCH_CAMAL) {
     TLayout t;
     size_t p = 0, r = 0;
     int zi = 0;
@@ -38,7 +38,7 @@ TLayout make_layout(int k) {
     for (int b = 0; b < 3; ++b) {
         for (int i = 0; i < 3; ++i) {
             const ConvShape& c = kConvs[3 * b + i];
-            add(t.conv[3 * b + i], c.cin, c.cout, c.k < 0 ? k : c.k);
+            add(t.conv[3 * b + i], c.cin, c.cout, conv_ks(arch, 3 * b + i, k));
         }
         if (b == 0) add(t.res[0], 1, C1, 1);
         if (b == 1) add(t.res[1], C1, C2, 1);
@@ -54,6 +54,8 @@ TLayout make_layout(int k) {
 
 struct camal_trainer {
     int device = 0, k = 0, maxB = 0, maxL = 0, num_cu = 256;
+    int arch = CAMAL_ARCH_CAMAL;    // CAMAL_ARCH_RESNET: kernels 7/5/3 and zeros outside the window (classifiers/resnet.py)
+    bool zpad() const { return arch == CAMAL_ARCH_RESNET; }
     size_t lds_per_cu = 160 * 1024;
     TLayout lay;
     std::vector<void*> owned;
@@ -124,9 +126,10 @@ int t_conv_fwd(camal_trainer* t, hipStream_t s, const TLayer& l, const float* pa
                float* zout, int B, int L) {
     const float* bias = params + l.b;
     const int pad = l.ks >> 1;
-    if (l.cin == C1 && l.cout == C1) return t_conv<C1, C1, false>(t, s, wpack, bias, l.ks, in, nullptr, zout, B, L, L, pad, nullptr);
-    if (l.cin == C1 && l.cout == C2) return t_conv<C1, C2, false>(t, s, wpack, bias, l.ks, in, nullptr, zout, B, L, L, pad, nullptr);
-    return t_conv<C2, C2, false>(t, s, wpack, bias, l.ks, in, nullptr, zout, B, L, L, pad, nullptr);
+    const float* zr = t->zpad() ? t->zeros : nullptr;  // what the layer reads outside the window
+    if (l.cin == C1 && l.cout == C1) return t_conv<C1, C1, false>(t, s, wpack, bias, l.ks, in, nullptr, zout, B, L, L, pad, zr);
+    if (l.cin == C1 && l.cout == C2) return t_conv<C1, C2, false>(t, s, wpack, bias, l.ks, in, nullptr, zout, B, L, L, pad, zr);
+    return t_conv<C2, C2, false>(t, s, wpack, bias, l.ks, in, nullptr, zout, B, L, L, pad, zr);
 }
 
 template <int C>
@@ -193,7 +196,7 @@ int t_wgrad(camal_trainer* t, hipStream_t s, const TLayer& l, const float* dz, c
         const dim3 g(CI / 32, ng, nsplit), blk(CO * 2);
         switch (nhi_taps) {
 #define CAMAL_WG_CASE(NT) \
-    case NT: hipLaunchKernelGGL((wgrad_kernel<CI, CO, NT>), g, blk, 0, s, dz, ain, t->wg_part, B, L, l.ks, wps, n_hi); break;
+    case NT: hipLaunchKernelGGL((wgrad_kernel<CI, CO, NT>), g, blk, 0, s, dz, ain, t->wg_part, B, L, l.ks, wps, n_hi, t->zpad()); break;
             CAMAL_WG_CASE(1) CAMAL_WG_CASE(2) CAMAL_WG_CASE(3) CAMAL_WG_CASE(4)
             CAMAL_WG_CASE(5) CAMAL_WG_CASE(6) CAMAL_WG_CASE(7) CAMAL_WG_CASE(8)
 #undef CAMAL_WG_CASE
@@ -214,7 +217,7 @@ int t_wgrad(camal_trainer* t, hipStream_t s, const TLayer& l, const float* dz, c
 
 int t_stem_wgrad(camal_trainer* t, hipStream_t s, const TLayer& l, const float* dz, const float* x, float* grads, int B, int L) {
     const int nseg = stem_nseg(L);
-    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(B, nseg), dim3(256), 0, s, dz, x, t->stem_part, L, l.ks);
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(B, nseg), dim3(256), 0, s, dz, x, t->stem_part, L, l.ks, t->zpad());
     hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(l.ks), dim3(256), 0, s, t->stem_part, B * nseg, l.ks, grads + l.w,
                        grads + l.b);
     HIP_TRY(hipGetLastError());
@@ -227,6 +230,13 @@ int t_dgrad(camal_trainer* t, hipStream_t s, const TLayer& l, const float* param
             float* dx, int B, int L) {
     const int pad = l.ks >> 1, Lp = L + 2 * pad;
     int r;
+    if (t->zpad()) {
+        // zero padding has no fold: the adjoint is the "same" correlation with the flipped, transposed weights,
+        // dz read as zeros outside the window (ks odd: ks - 1 - pad = pad)
+        if (l.cin == C1 && l.cout == C1) return t_conv<C1, C1, false>(t, s, wflip, t->zeros, l.ks, dz, nullptr, dx, B, L, L, pad, t->zeros);
+        if (l.cin == C1 && l.cout == C2) return t_conv<C2, C1, false>(t, s, wflip, t->zeros, l.ks, dz, nullptr, dx, B, L, L, pad, t->zeros);
+        return t_conv<C2, C2, false>(t, s, wflip, t->zeros, l.ks, dz, nullptr, dx, B, L, L, pad, t->zeros);
+    }
     if (l.cin == C1 && l.cout == C1) r = t_conv<C1, C1, false>(t, s, wflip, t->zeros, l.ks, dz, nullptr, t->gXP, B, Lp, L, 2 * pad, t->zeros);
     else if (l.cin == C1 && l.cout == C2) r = t_conv<C2, C1, false>(t, s, wflip, t->zeros, l.ks, dz, nullptr, t->gXP, B, Lp, L, 2 * pad, t->zeros);
     else r = t_conv<C2, C2, false>(t, s, wflip, t->zeros, l.ks, dz, nullptr, t->gXP, B, Lp, L, 2 * pad, t->zeros);
@@ -243,10 +253,19 @@ int t_dgrad(camal_trainer* t, hipStream_t s, const TLayer& l, const float* param
 extern "C" {
 
 size_t camal_trainer_param_count(int kernel_size) { return make_layout(kernel_size).n_params; }
+size_t camal_trainer_param_count_arch(int kernel_size, int arch) {
+    return arch == CAMAL_ARCH_CAMAL || arch == CAMAL_ARCH_RESNET ? make_layout(kernel_size, arch).n_params : 0;
+}
 size_t camal_trainer_running_count(void) { return make_layout(7).n_running; }
 
 int camal_trainer_create(int device_id, int kernel_size, int max_batch, int max_len, camal_trainer** out) {
+    return camal_trainer_create_arch(device_id, kernel_size, max_batch, max_len, CAMAL_ARCH_CAMAL, out);
+}
+
+int camal_trainer_create_arch(int device_id, int kernel_size, int max_batch, int max_len, int arch, camal_trainer** out) {
     if (!out) return fail(CAMAL_ERR_ARG, "null argument");
+    if (arch != CAMAL_ARCH_CAMAL && arch != CAMAL_ARCH_RESNET) return fail(CAMAL_ERR_ARG, "arch must be 0 (CamALResNet) or 1 (ResNet)");
+    if (arch == CAMAL_ARCH_RESNET && kernel_size != 7) return fail(CAMAL_ERR_ARG, "the ResNet variant has kernel sizes 7, 5, 3: pass 7");
     if (kernel_size < 1 || kernel_size > 63 || !(kernel_size & 1)) return fail(CAMAL_ERR_ARG, "kernel size must be odd and in 1..63");
     if (max_batch < 1 || max_len < 1) return fail(CAMAL_ERR_ARG, "max_batch and max_len must be >= 1");
     int ndev = 0;
@@ -254,8 +273,8 @@ int camal_trainer_create(int device_id, int kernel_size, int max_batch, int max_
     if (device_id < 0 || device_id >= ndev) return fail(CAMAL_ERR_ARG, "no such device");
     HIP_TRY(hipSetDevice(device_id));
     camal_trainer* t = new camal_trainer();
-    t->device = device_id; t->k = kernel_size; t->maxB = max_batch; t->maxL = max_len;
-    t->lay = make_layout(kernel_size);
+    t->device = device_id; t->k = kernel_size; t->maxB = max_batch; t->maxL = max_len; t->arch = arch;
+    t->lay = make_layout(kernel_size, arch);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) t->num_cu = prop.multiProcessorCount;
     const size_t N = (size_t)max_batch * max_len;
@@ -330,7 +349,7 @@ int camal_train_fwd_bwd(camal_trainer* t, const float* params, float* running, c
         const TLayer& l0 = Y.conv[0];
         const TLayer& lr = Y.res[0];
         hipLaunchKernelGGL(stem_train_kernel, dim3((L + 63) / 64, B), dim3(256), 0, s, x, params + l0.w, params + l0.b,
-                           params + lr.w, params + lr.b, t->z[l0.zi], t->z[lr.zi], L, l0.ks);
+                           params + lr.w, params + lr.b, t->z[l0.zi], t->z[lr.zi], L, l0.ks, t->zpad());
         HIP_TRY(hipGetLastError());
         if ((r = t_bn_stats_any(t, s, t->z[l0.zi], N, l0, momentum, running))) return r;
         if ((r = t_bn_stats_any(t, s, t->z[lr.zi], N, lr, momentum, running))) return r;

@@ -54,14 +54,14 @@ __global__ void pack_w_kernel(PackJobs jobs) {
 __global__ __launch_bounds__(256) void stem_train_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, const float* __restrict__ wr,
                                                          const float* __restrict__ br, float* __restrict__ z0,
-                                                         float* __restrict__ zr, int L, int ks) {
+                                                         float* __restrict__ zr, int L, int ks, bool zero_pad) {
     __shared__ float xs[64 + 64];
     const int b = blockIdx.y, t0 = blockIdx.x * 64, pad = ks >> 1;
     const float* xb = x + (size_t)b * L;
     for (int i = threadIdx.x; i < 64 + ks - 1; i += 256) {
-        int p = t0 - pad + i;
-        p = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
-        xs[i] = xb[p];
+        const int p = t0 - pad + i;
+        const int pc = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
+        xs[i] = (zero_pad && pc != p) ? 0.f : xb[pc];  // zero_pad: classifiers/resnet.py:62
     }
     __syncthreads();
     const int cg = threadIdx.x & 15, tq = threadIdx.x >> 4;
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void fold_edges_kernel(const float* __restrict
 template <int CIN, int COUT, int NTAP>
 __device__ __forceinline__ void wgrad_body(float (*s_dz)[COUT], float (*s_a)[32], const float* __restrict__ dz,
                                            const float* __restrict__ ain, float* __restrict__ part, int B, int L, int ks,
-                                           int windows_per_split, int j0) {
+                                           int windows_per_split, int j0, bool zero_pad) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int ci0 = blockIdx.x * 32;
@@ -449,14 +449,15 @@ __device__ __forceinline__ void wgrad_body(float (*s_dz)[COUT], float (*s_a)[32]
             rdz[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (t < L) rdz[u] = *reinterpret_cast<const float4*>(dz + ((size_t)b * L + t) * COUT + c4);
         }
-        // input rows t0 + j0 - pad .. (+ TT + ntap - 2), clamped = replicate padding, 32 channels
+        // input rows t0 + j0 - pad .. (+ TT + ntap - 2), clamped = replicate padding (zero_pad: zeros outside), 32 channels
 #pragma unroll
         for (int u = 0; u < A_PER; ++u) {
             const int q = threadIdx.x + u * NTH;
             if (q < A_Q) {
-                int p = t0 + j0 - pad + (q >> 3);
-                p = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
-                ra[u] = *reinterpret_cast<const float4*>(ain + ((size_t)b * L + p) * CIN + ci0 + (q & 7) * 4);
+                const int p = t0 + j0 - pad + (q >> 3);
+                const int pc = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
+                ra[u] = *reinterpret_cast<const float4*>(ain + ((size_t)b * L + pc) * CIN + ci0 + (q & 7) * 4);
+                if (zero_pad && pc != p) ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     };
@@ -505,16 +506,16 @@ __device__ __forceinline__ void wgrad_body(float (*s_dz)[COUT], float (*s_a)[32]
 template <int CIN, int COUT, int NHI>
 __global__ __launch_bounds__(COUT * 2) void wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ ain,
                                                          float* __restrict__ part, int B, int L, int ks,
-                                                         int windows_per_split, int n_hi) {
+                                                         int windows_per_split, int n_hi, bool zero_pad) {
     __shared__ float s_dz[WG_TT][COUT];
     __shared__ float s_a[WG_TT + WG_TAPS][32];
     const int y = blockIdx.y;
     if (y < n_hi) {
-        wgrad_body<CIN, COUT, NHI>(s_dz, s_a, dz, ain, part, B, L, ks, windows_per_split, y * NHI);
+        wgrad_body<CIN, COUT, NHI>(s_dz, s_a, dz, ain, part, B, L, ks, windows_per_split, y * NHI, zero_pad);
     } else {
         if constexpr (NHI > 1)
             wgrad_body<CIN, COUT, NHI - 1>(s_dz, s_a, dz, ain, part, B, L, ks, windows_per_split,
-                                           n_hi * NHI + (y - n_hi) * (NHI - 1));
+                                           n_hi * NHI + (y - n_hi) * (NHI - 1), zero_pad);
     }
 }
 
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 __host__ __device__ inline int stem_nseg(int L) { return (L + STEM_SEG_LEN - 1) / STEM_SEG_LEN; }
 
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x,
-                                                         float* __restrict__ part, int L, int ks) {
+                                                         float* __restrict__ part, int L, int ks, bool zero_pad) {
     __shared__ float red[4][64];
     __shared__ float xs[STEM_SEG_LEN + 64 + 8];
     const int b = blockIdx.x, seg = blockIdx.y, co = threadIdx.x & 63, ph = threadIdx.x >> 6, pad = ks >> 1;
@@ -565,9 +566,9 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     const float* dzb = dz + (size_t)b * L * 64;
     // xs[r] = x[clamp(t0 - pad + r)]; the rows past the last tap only meet accumulators that are never stored
     for (int r = threadIdx.x; r < STEM_SEG_LEN + 64 + 8; r += 256) {
-        int p = t0 - pad + r;
-        p = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
-        xs[r] = xb[p];
+        const int p = t0 - pad + r;
+        const int pc = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
+        xs[r] = (zero_pad && pc != p) ? 0.f : xb[pc];
     }
     __syncthreads();
     float* po = part + ((size_t)b * gridDim.y + seg) * ks * 64;

@@ -127,9 +127,6 @@ class CamALResNet:
     def forward(self, x):
         """x [B,1,L] (or [B,L]) -> logits [B,2] on the device (camal_resnet.py:21-23)."""
         if self.training:
-            if self._arch != weights.ARCH_CAMAL:
-                raise NotImplementedError("the HIP training step implements CamALResNet (what CamAL.train builds, "
-                                          "reference core.py:106); ResNet runs in eval() mode")
             from .trainer import forward_train
             return forward_train(self, x)
         logits, _ = self.engine().forward_cam(x, want_cam=False)
@@ -141,8 +138,9 @@ class CamALResNet:
 class ResNet(CamALResNet):
     """Mirror of the reference's second classifier (``src/models/camal/classifiers/resnet.py:3-23``): the same three
     ResNetBlocks, state-dict key names and head, with kernel sizes 7, 5, 3 in every block (:31) and zero ``"same"``
-    padding (:62) instead of the replicate mode.  Inference (``eval()``), CAM and the ensemble post-processing run
-    on it through the same entry points (``camal_create_arch(..., CAMAL_ARCH_RESNET)``)."""
+    padding (:62) instead of the replicate mode.  Inference (``eval()``), CAM, the ensemble post-processing and the
+    training step run on it through the same entry points (``camal_create_arch`` / ``camal_trainer_create_arch`` with
+    ``CAMAL_ARCH_RESNET``)."""
     _arch = weights.ARCH_RESNET
 
     def __init__(self, in_channels: int = 1, mid_channels: int = 64, nb_class: int = 2):

@@ -102,13 +102,16 @@ class TrainEngine:
         if (model.in_channels, model.mid_channels, model.nb_class) != (1, 64, 2):
             raise NotImplementedError("the HIP training path implements in_channels=1, mid_channels=64, nb_class=2")
         self.k = model.kernel_size
-        self.keys = weights.trainable_keys(self.k)
+        self.arch = getattr(model, "_arch", weights.ARCH_CAMAL)
+        arch_id = {weights.ARCH_CAMAL: _lib.ARCH_CAMAL, weights.ARCH_RESNET: _lib.ARCH_RESNET}[self.arch]
+        self.keys = weights.trainable_keys(self.k, arch=self.arch)
         self.bn_prefixes = [k[:-len(".running_mean")] for k in model._params if k.endswith("running_mean")]
-        self.n = int(self.lib.camal_trainer_param_count(self.k))
+        self.n = int(self.lib.camal_trainer_param_count_arch(self.k, arch_id))
         assert self.n == sum(model._params[k].size for k in self.keys)
         self.n_running = int(self.lib.camal_trainer_running_count())
         h = C.c_void_p()
-        _lib.check(self.lib.camal_trainer_create(self.device.index, self.k, int(max_batch), int(length), C.byref(h)))
+        _lib.check(self.lib.camal_trainer_create_arch(self.device.index, self.k, int(max_batch), int(length), arch_id,
+                                                      C.byref(h)))
         self._h = h
         self.max_batch, self.length = int(max_batch), int(length)
         with torch.cuda.device(self.device):

@@ -73,9 +73,9 @@ def state_dict_spec(kernel_size, in_channels=1, mid_channels=64, nb_class=2, arc
     return spec
 
 
-def trainable_keys(kernel_size, in_channels=1, mid_channels=64):
+def trainable_keys(kernel_size, in_channels=1, mid_channels=64, arch=ARCH_CAMAL):
     """Keys of ``model.parameters()`` in torch's registration order (what AdamW sees)."""
-    return [k for k in state_dict_spec(kernel_size, in_channels, mid_channels)
+    return [k for k in state_dict_spec(kernel_size, in_channels, mid_channels, arch=arch)
             if not (k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"))]
 
 

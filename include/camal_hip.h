@@ -194,6 +194,11 @@ typedef struct camal_trainer camal_trainer;
 size_t camal_trainer_param_count(int kernel_size);   /* number of trainable floats P(k)        */
 size_t camal_trainer_running_count(void);            /* floats of BN running statistics        */
 int camal_trainer_create(int device_id, int kernel_size, int max_batch, int max_len, camal_trainer** out);
+/* The same for either classifier (CAMAL_ARCH_RESNET: classifiers/resnet.py's ResNet trained by the same
+ * BasedClassifTrainer.__train body, torch_trainer.py:273-300; kernel_size must be 7): parameter order = that model's
+ * model.parameters(), layers read zeros outside the window, so the data gradient needs no edge fold.            */
+int camal_trainer_create_arch(int device_id, int kernel_size, int max_batch, int max_len, int arch, camal_trainer** out);
+size_t camal_trainer_param_count_arch(int kernel_size, int arch); /* 0 for an unknown arch */
 int camal_trainer_destroy(camal_trainer* t);
 
 /* One forward(+backward) pass on a batch.

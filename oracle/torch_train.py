@@ -21,7 +21,8 @@ class FunctionalResNet:
     def __init__(self, sd):
         sd = weights.to_numpy_state_dict(sd)
         self.k = weights.kernel_size_of(sd)
-        self.keys = weights.trainable_keys(self.k)
+        self.arch = weights.arch_of(sd)  # "resnet": classifiers/resnet.py's ResNet, zero "same" padding (:62)
+        self.keys = weights.trainable_keys(self.k, arch=self.arch)
         self.p = {k: torch.tensor(np.array(sd[k]), dtype=torch.float32, requires_grad=k in self.keys)
                   for k in sd if not k.endswith("num_batches_tracked")}
         self.nbt = int(sd["layers.0.layers.0.layers.1.num_batches_tracked"])
@@ -44,7 +45,8 @@ class FunctionalResNet:
                 pre = f"layers.{b}.layers.{i}"
                 w = p[pre + ".layers.0.weight"]
                 k = w.shape[-1]
-                h = F.conv1d(F.pad(h, (k // 2, k // 2), mode="replicate"), w, p[pre + ".layers.0.bias"])
+                hp = F.pad(h, (k // 2, k // 2)) if self.arch == weights.ARCH_RESNET else F.pad(h, (k // 2, k // 2), mode="replicate")
+                h = F.conv1d(hp, w, p[pre + ".layers.0.bias"])
                 h = F.relu(self._bn(h, pre + ".layers.1", training))
             if f"layers.{b}.residual.0.weight" in p:
                 r = F.conv1d(x, p[f"layers.{b}.residual.0.weight"], p[f"layers.{b}.residual.0.bias"])

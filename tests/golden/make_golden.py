@@ -141,18 +141,24 @@ def run_case(name, data, seed, gain, w_ma=5, gated=False, members=None):
           f"size={os.path.getsize(os.path.join(HERE, name + '.npz')) / 1024:.0f} KB")
 
 
-def train_case(name, k, seed, n, length, batch, epochs, lr=1e-3):
+def train_case(name, k, seed, n, length, batch, epochs, lr=1e-3, arch=weights.ARCH_CAMAL):
     """Training fixtures from the reference's own classes: one backward pass of CamALResNet in
     train() mode under nn.CrossEntropyLoss (torch_trainer.py:288-291), and `epochs` epochs of
     BasedClassifTrainer.train (AdamW, torch_trainer.py:92-171,273-300) on an unshuffled loader."""
     from src.helpers.torch_trainer import BasedClassifTrainer
     from src.helpers.torch_dataset import TSDataset
     x, y = synth.ideal_windows(n, length, seed=seed)
-    sd0 = weights.make_state_dict(k, seed=seed, head_gain=1.0)
-    keys = weights.trainable_keys(k)
+    sd0 = weights.make_state_dict(k, seed=seed, head_gain=1.0, arch=arch)
+    keys = weights.trainable_keys(k, arch=arch)
+    if arch == weights.ARCH_RESNET:  # classifiers/resnet.py's ResNet under the same trainer
+        from src.models.camal.classifiers.resnet import ResNet
+        assert k == 7
+        make_model = ResNet
+    else:
+        make_model = lambda: CamALResNet(kernel_size=k)  # noqa: E731
 
     # (1) one forward/backward on the first batch
-    m = CamALResNet(kernel_size=k)
+    m = make_model()
     m.load_state_dict(to_torch_sd(sd0))
     m.train()
     xb = torch.from_numpy(x[:batch, None, :]).float()
@@ -167,6 +173,7 @@ def train_case(name, k, seed, n, length, batch, epochs, lr=1e-3):
     run_keys = [kk for kk in sd1 if kk.endswith("running_mean") or kk.endswith("running_var")]
     out = dict(
         k=np.array(k), seed=np.array(seed), n=np.array(n), length=np.array(length), batch=np.array(batch),
+        resnet_variant=np.array(arch == weights.ARCH_RESNET),
         epochs=np.array(epochs), lr=np.array(lr),
         step1_loss=np.array(float(loss)), step1_logits=logits.detach().numpy(),
         step1_grad_norms=np.array([np.linalg.norm(grads[kk].astype(np.float64)) for kk in keys]),
@@ -176,7 +183,7 @@ def train_case(name, k, seed, n, length, batch, epochs, lr=1e-3):
     )
 
     # (2) the reference trainer for a few epochs
-    m2 = CamALResNet(kernel_size=k)
+    m2 = make_model()
     m2.load_state_dict(to_torch_sd(sd0))
     loader = torch.utils.data.DataLoader(TSDataset(x, y), batch_size=batch, shuffle=False)
     tr = BasedClassifTrainer(m2, train_loader=loader, valid_loader=None, learning_rate=lr, weight_decay=0,
@@ -298,6 +305,8 @@ def resnet_variant_cases():
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "resnetvar":
         return resnet_variant_cases()
+    if len(sys.argv) > 1 and sys.argv[1] == "trainvar":
+        return train_case("train_resnetvar_l80", k=7, seed=203, n=36, length=80, batch=12, epochs=2, arch=weights.ARCH_RESNET)
     if len(sys.argv) > 1 and sys.argv[1] == "metrics":
         return metrics_case()
     if len(sys.argv) > 1 and sys.argv[1] == "windows":
@@ -307,6 +316,7 @@ def main():
     resnet_variant_cases()
     train_case("train_k7_l96", k=7, seed=201, n=48, length=96, batch=16, epochs=2)
     train_case("train_k25_l70", k=25, seed=202, n=24, length=70, batch=12, epochs=1)
+    train_case("train_resnetvar_l80", k=7, seed=203, n=36, length=80, batch=12, epochs=2, arch=weights.ARCH_RESNET)
     # 1. the BASELINE config-1 shape, shrunk: full ensemble, float32 data
     run_case("ensemble_l256", synth.ukdale_windows(12, 256, seed=11), seed=101, gain=2.0)
     # 2. float64 data (output dtype follows the input, quirk 9), ragged length (not a tile multiple)

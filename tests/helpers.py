@@ -50,8 +50,17 @@ def train_case_inputs(case):
     from camal_amd import synth
     k, seed = int(case["k"]), int(case["seed"])
     x, y = synth.ideal_windows(int(case["n"]), int(case["length"]), seed=seed)
-    sd0 = weights.make_state_dict(k, seed=seed, head_gain=1.0)
+    arch = weights.ARCH_RESNET if "resnet_variant" in case and bool(case["resnet_variant"]) else weights.ARCH_CAMAL
+    sd0 = weights.make_state_dict(k, seed=seed, head_gain=1.0, arch=arch)
     return k, x, y, sd0
+
+
+def model_for(sd0):
+    """The mirror class a state dict belongs to (CamALResNet, or ResNet for the 7/5/3 zero-padded variant)."""
+    from camal_amd.resnet import CamALResNet, ResNet
+    if weights.arch_of(sd0) == weights.ARCH_RESNET:
+        return ResNet()
+    return CamALResNet(kernel_size=weights.kernel_size_of(sd0))
 
 
 def is_bn_fed_bias(key):

@@ -13,9 +13,9 @@ CASES = golden_cases("train_")
 
 
 def _engine(sd0, k, B, L):
-    from camal_amd.resnet import CamALResNet
     from camal_amd.trainer import TrainEngine
-    m = CamALResNet(kernel_size=k)
+    from tests.helpers import model_for
+    m = model_for(sd0)
     m.to("cuda:0")
     m.load_state_dict(sd0)
     return m, TrainEngine(m, "cuda:0", B, L)
@@ -86,7 +86,8 @@ def test_trainer_mirror_vs_reference_history(name):
     from camal_amd.trainer import BasedClassifTrainer, TSLoader
     c = load_case(name)
     k, x, y, sd0 = train_case_inputs(c)
-    m = CamALResNet(kernel_size=k)
+    from tests.helpers import model_for
+    m = model_for(sd0)
     m.load_state_dict(sd0)
     loader = TSLoader(x, y, batch_size=int(c["batch"]), shuffle=False)
     tr = BasedClassifTrainer(m, train_loader=loader, valid_loader=None, learning_rate=float(c["lr"]), weight_decay=0,
