@@ -239,6 +239,11 @@ def test_resnet_variant_mirror_class(torch_cuda):
     m.eval()
     lg = m(c["data"].astype(np.float32)[:, None, :]).cpu().numpy()
     assert rel_err(lg.T, c["logits"][0].T) < REL_TOL_FP32
+    # train() mode: batch-statistics forward through the training entry points, against the torch restatement
+    import torch
+    from oracle.torch_train import FunctionalResNet
     m.train()
-    with pytest.raises(NotImplementedError):
-        m(c["data"].astype(np.float32)[:, None, :])
+    lt = m(c["data"].astype(np.float32)[:, None, :]).cpu().numpy()
+    with torch.no_grad():
+        ref = FunctionalResNet(resnetvar_state_dicts(c)[0]).forward(torch.from_numpy(c["data"].astype(np.float32))).numpy()
+    assert rel_err(lt.T, ref.T) < REL_TOL_FP32
