@@ -82,9 +82,13 @@ def train_main(args, wl, rank, local_rank, world, dev, dist):
         engines.append(TrainEngine(m, dev, B, L))
 
     def step():
+        # a member's gradient all-reduce (N > 1) runs under the next member's forward and backward
+        pending = []
         for e in engines:
             e.forward_backward(x, y)
-            e.optimizer_step(1e-3, 1e-2)
+            pending.append(e.start_grad_allreduce())
+        for e, p in zip(engines, pending):
+            e.optimizer_step(1e-3, 1e-2, pending=p)
 
     def sync():
         torch.cuda.synchronize()

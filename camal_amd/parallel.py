@@ -92,6 +92,32 @@ def allreduce_mean_(flat: torch.Tensor, dist=None):
     return flat
 
 
+class PendingMean:
+    """An in-flight ``allreduce_mean_start``: ``wait()`` makes the current stream wait for the collective (the host
+    does not block on "nccl") and finishes the mean."""
+
+    def __init__(self, flat, work, world):
+        self.flat, self.work, self.world = flat, work, world
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.flat.div_(self.world)
+            self.work = None
+        return self.flat
+
+
+def allreduce_mean_start(flat: torch.Tensor, dist=None) -> PendingMean:
+    """Start the mean over ranks of a flat gradient bucket without waiting for it: the collective runs on the
+    backend's own stream behind the work already queued on the current one, so the next member's forward and backward
+    overlap it (xGMI all-reduces of 2-4 MB are latency-bound).  Nothing may touch ``flat`` before ``wait()``."""
+    if dist is None:
+        import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return PendingMean(flat, None, 1)
+    return PendingMean(flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), dist.get_world_size())
+
+
 def max_over_ranks(value: float, device=None, dist=None) -> float:
     if dist is None:
         import torch.distributed as dist

@@ -202,8 +202,17 @@ class TrainEngine:
 
     data_parallel = True  # False: this rank trains the member alone (members spread over ranks, CamAL.train)
 
-    def optimizer_step(self, lr, weight_decay):
-        if self.data_parallel:
+    def start_grad_allreduce(self):
+        """Begin this member's gradient all-reduce and return at once; hand the result to ``optimizer_step(...,
+        pending=...)`` later (callers that step several members overlap it with the next member's work)."""
+        if not self.data_parallel:
+            return parallel.PendingMean(self.grads, None, 1)
+        return parallel.allreduce_mean_start(self.grads)
+
+    def optimizer_step(self, lr, weight_decay, pending=None):
+        if pending is not None:
+            pending.wait()
+        elif self.data_parallel:
             parallel.allreduce_mean_(self.grads)  # no-op unless torch.distributed is initialised
         self.step_count += 1
         with torch.cuda.device(self.device):

@@ -40,6 +40,12 @@ def _worker(rank, world, port, n, tmp):
         g = torch.full((1000,), float(rank + 1))
         parallel.allreduce_mean_(g)
         assert torch.allclose(g, torch.full((1000,), (1 + world) / 2.0))
+        # the same, started early and waited for later (several buckets in flight, as bench.py's training step does)
+        gs = [torch.full((257,), float((rank + 1) * (i + 1))) for i in range(3)]
+        pend = [parallel.allreduce_mean_start(t) for t in gs]
+        for i, p in enumerate(pend):
+            assert torch.allclose(p.wait(), torch.full((257,), (i + 1) * (1 + world) / 2.0))
+            assert p.wait() is gs[i]  # a second wait is a no-op
         # timing reduce
         t = parallel.max_over_ranks(0.1 * (rank + 1))
         assert abs(t - 0.1 * world) < 1e-12
