@@ -53,12 +53,15 @@ def test_one_step_vs_reference_fixture(name):
     eng.close()
 
 
-def test_every_gradient_tensor_vs_oracle():
+# L > 128: several segments per window in the Cin = 1 weight gradient; k = 9 / 15 / 25: two to four tap groups in one
+# weight-gradient launch; "resnet": classifiers/resnet.py's block (7/5/3, zero padding)
+@pytest.mark.parametrize("k,B,L,arch", [(9, 10, 77, "camal"), (5, 6, 300, "camal"), (25, 5, 257, "camal"),
+                                        (15, 3, 129, "camal"), (7, 9, 200, "resnet"), (7, 4, 131, "resnet")])
+def test_every_gradient_tensor_vs_oracle(k, B, L, arch):
     from camal_amd import synth
     from oracle import torch_train
-    k, B, L = 9, 10, 77
     x, y = synth.ideal_windows(B, L, seed=5)
-    sd0 = weights.make_state_dict(k, seed=31, head_gain=1.0)
+    sd0 = weights.make_state_dict(k, seed=31, head_gain=1.0, arch=arch)
     loss_ref, nc_ref, g_ref, sd1 = torch_train.loss_and_grads(sd0, x, y)
     m, eng = _engine(sd0, k, B, L)
     loss, ncorrect = eng.forward_backward(x, y)
