@@ -56,7 +56,9 @@ def test_one_step_vs_reference_fixture(name):
 # L > 128: several segments per window in the Cin = 1 weight gradient; k = 9 / 15 / 25: two to four tap groups in one
 # weight-gradient launch; "resnet": classifiers/resnet.py's block (7/5/3, zero padding)
 @pytest.mark.parametrize("k,B,L,arch", [(9, 10, 77, "camal"), (5, 6, 300, "camal"), (25, 5, 257, "camal"),
-                                        (15, 3, 129, "camal"), (7, 9, 200, "resnet"), (7, 4, 131, "resnet")])
+                                        (15, 3, 129, "camal"), (7, 9, 200, "resnet"), (7, 4, 131, "resnet"),
+                                        # the bench's batch: several windows per weight-gradient split, ragged last split
+                                        (25, 128, 64, "camal"), (15, 100, 40, "camal")])
 def test_every_gradient_tensor_vs_oracle(k, B, L, arch):
     from camal_amd import synth
     from oracle import torch_train
