@@ -481,7 +481,7 @@ __device__ __forceinline__ void wgrad_body(float (*s_dz)[COUT], float (*s_a)[32]
             __syncthreads();
             if (t0 + WG_TT < L) fetch(b, t0 + WG_TT);
             else if (b + 1 < b1) fetch(b + 1, 0);
-#pragma unroll 4
+#pragma unroll 16
             for (int s = 0; s < WG_TT / 2; ++s) {
                 const float av = s_dz[2 * s + h][32 * wave + i];
 #pragma unroll
