@@ -102,27 +102,36 @@ __global__ __launch_bounds__(256) void stem_train_kernel(const float* __restrict
 #define BN_ROWS_PER_BLOCK 64
 #define BN_FINAL_THREADS 1024
 
+// Lane = 4 channels x every G-th row of the block's 64 (16-byte loads, all of a lane's rows in flight at once:
+// a channel per lane with dword loads moved 3.8 TB/s).
 template <int C>
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ z, int N,
                                                                double* __restrict__ partial /*[grid][C][2]*/) {
-    constexpr int G = 256 / C;
-    __shared__ double sh[256][2];
-    const int c = threadIdx.x % C, g = threadIdx.x / C;
+    constexpr int Q = C / 4, G = 256 / Q, RPL = BN_ROWS_PER_BLOCK / G;  // quads per row, row groups, rows per lane
+    static_assert(RPL * G == BN_ROWS_PER_BLOCK, "rows divide over the row groups");
+    __shared__ float sh[G][C][2];
+    const int c4 = (threadIdx.x % Q) * 4, g = threadIdx.x / Q;
     const int r0 = blockIdx.x * BN_ROWS_PER_BLOCK;
-    const int r1 = min(N, r0 + BN_ROWS_PER_BLOCK);
-    float s = 0.f, ss = 0.f;
-    for (int r = r0 + g; r < r1; r += G) {
-        const float v = z[(size_t)r * C + c];
-        s += v;
-        ss = fmaf(v, v, ss);
+    float v[RPL][4];
+#pragma unroll
+    for (int u = 0; u < RPL; ++u) {
+        const int r = r0 + g + u * G;
+        v[u][0] = v[u][1] = v[u][2] = v[u][3] = 0.f;
+        if (r < N) load4(z + (size_t)r * C + c4, v[u]);
     }
-    sh[threadIdx.x][0] = (double)s;
-    sh[threadIdx.x][1] = (double)ss;
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < RPL; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s[k] += v[u][k]; ss[k] = fmaf(v[u][k], v[u][k], ss[k]); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sh[g][c4 + k][0] = s[k]; sh[g][c4 + k][1] = ss[k]; }
     __syncthreads();
-    if (g == 0) {
+    if (threadIdx.x < C) {
+        const int c = threadIdx.x;
         double a = 0.0, b = 0.0;
 #pragma unroll
-        for (int k = 0; k < G; ++k) { a += sh[k * C + c][0]; b += sh[k * C + c][1]; }
+        for (int k = 0; k < G; ++k) { a += (double)sh[k][c][0]; b += (double)sh[k][c][1]; }
         partial[((size_t)blockIdx.x * C + c) * 2 + 0] = a;
         partial[((size_t)blockIdx.x * C + c) * 2 + 1] = b;
     }
@@ -216,27 +225,42 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              int N, int L, float inv_len, double* __restrict__ partial) {
-    constexpr int G = 256 / C;
-    __shared__ double sh[256][2];
-    const int c = threadIdx.x % C, g = threadIdx.x / C;
+    constexpr int Q = C / 4, G = 256 / Q, RPL = BN_ROWS_PER_BLOCK / G;  // as bn_stats_partial_kernel
+    __shared__ float sh[G][C][2];
+    const int c4 = (threadIdx.x % Q) * 4, g = threadIdx.x / Q;
     const int r0 = blockIdx.x * BN_ROWS_PER_BLOCK;
-    const int r1 = min(N, r0 + BN_ROWS_PER_BLOCK);
-    const float m = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
-    float s1 = 0.f, s2 = 0.f;
-    for (int r = r0 + g; r < r1; r += G) {
-        const float xh = (z[(size_t)r * C + c] - m) * is;
-        float d = BCAST ? da[(size_t)(r / L) * C + c] * inv_len : da[(size_t)r * C + c];
-        if (RELU) d = (xh * ga + be) > 0.f ? d : 0.f;
-        s1 += d;
-        s2 = fmaf(d, xh, s2);
+    float m[4], is[4], ga[4], be[4];
+    load4(mean + c4, m); load4(invstd + c4, is); load4(gamma + c4, ga); load4(beta + c4, be);
+    float zv[RPL][4], dv[RPL][4];
+#pragma unroll
+    for (int u = 0; u < RPL; ++u) {
+        const int r = r0 + g + u * G;
+        const int rc = r < N ? r : N - 1;  // a row past the end loads a valid address and counts for nothing
+        load4(z + (size_t)rc * C + c4, zv[u]);
+        load4(BCAST ? da + (size_t)(rc / L) * C + c4 : da + (size_t)rc * C + c4, dv[u]);
     }
-    sh[threadIdx.x][0] = (double)s1;
-    sh[threadIdx.x][1] = (double)s2;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < RPL; ++u) {
+        const bool live = r0 + g + u * G < N;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xh = (zv[u][k] - m[k]) * is[k];
+            float d = BCAST ? dv[u][k] * inv_len : dv[u][k];
+            if (RELU) d = (xh * ga[k] + be[k]) > 0.f ? d : 0.f;
+            d = live ? d : 0.f;
+            s1[k] += d;
+            s2[k] = fmaf(d, xh, s2[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sh[g][c4 + k][0] = s1[k]; sh[g][c4 + k][1] = s2[k]; }
     __syncthreads();
-    if (g == 0) {
+    if (threadIdx.x < C) {
+        const int c = threadIdx.x;
         double a = 0.0, b = 0.0;
 #pragma unroll
-        for (int k = 0; k < G; ++k) { a += sh[k * C + c][0]; b += sh[k * C + c][1]; }
+        for (int k = 0; k < G; ++k) { a += (double)sh[k][c][0]; b += (double)sh[k][c][1]; }
         partial[((size_t)blockIdx.x * C + c) * 2 + 0] = a;
         partial[((size_t)blockIdx.x * C + c) * 2 + 1] = b;
     }
