@@ -43,6 +43,8 @@ SIGNATURES = {
     "camal_windows_count": (_i, [C.c_longlong, _i, _i]),
     "camal_windows_workspace_bytes": (_sz, [_i]),
     "camal_build_windows": (_i, [_vp, _i, _i, C.c_longlong, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "camal_windows_static_scratch_bytes": (_sz, []),
+    "camal_build_windows_static": (_i, [_vp, _i, _i, C.c_longlong, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "camal_nilm_workspace_bytes": (_sz, [_sz]),
     "camal_nilm_sums": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp]),
     "camal_trainer_param_count": (_sz, [_i]),

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -775,19 +776,12 @@ int camal_windows_count(long long T, int W, int stride) {
     return n > 0x7fffffffLL ? 0x7fffffff : (int)n;
 }
 
-int camal_build_windows(const void* series, int series_is_f64, int n_rows, long long T, int W, int stride, int app,
-                        double stat1, double stat2, float* x_out, double* x64_out, int8_t* label_out, float* app_power_out,
-                        int8_t* app_state_out, int* index_out, int* count_out, void* workspace, size_t workspace_bytes,
-                        void* stream) {
-    if (!series || !x_out || !count_out || !workspace) return fail(CAMAL_ERR_ARG, "series_dev, x_out, count_out and workspace_dev are required");
-    if (n_rows < 1 || T < 1 || W < 1 || stride < 1) return fail(CAMAL_ERR_ARG, "n_rows, T, W and stride must be >= 1");
-    if (app < 1) return fail(CAMAL_ERR_ARG, "app is the 1-based appliance index");
-    if ((label_out || app_power_out || app_state_out) && 2 * app >= n_rows)
-        return fail(CAMAL_ERR_ARG, "the series has no (power, status) rows for that appliance");
-    if (stat2 == 0.0) return fail(CAMAL_ERR_ARG, "stat2 must not be 0");
-    const int n_wins = camal_windows_count(T, W, stride);
-    if (n_wins < 1) return fail(CAMAL_ERR_ARG, "the series is shorter than one window");
-    if (workspace_bytes < camal_windows_workspace_bytes(n_wins)) return fail(CAMAL_ERR_ARG, "workspace smaller than camal_windows_workspace_bytes(n_wins)");
+// shared body of camal_build_windows / camal_build_windows_static: `workspace` is device memory of at least
+// camal_windows_workspace_bytes(n_wins) bytes (checked by the callers)
+static int build_windows_impl(const void* series, int series_is_f64, int n_rows, long long T, int W, int stride, int app,
+                              double stat1, double stat2, float* x_out, double* x64_out, int8_t* label_out,
+                              float* app_power_out, int8_t* app_state_out, int* index_out, int* count_out, int n_wins,
+                              void* workspace, void* stream) {
     WinArgs a;
     a.s32 = series_is_f64 ? nullptr : (const float*)series;
     a.s64 = series_is_f64 ? (const double*)series : nullptr;
@@ -807,6 +801,84 @@ int camal_build_windows(const void* series, int series_is_f64, int n_rows, long 
     hipLaunchKernelGGL(win_copy_kernel, dim3(n_wins), dim3(256), 0, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+static int check_windows_args(const void* series, int n_rows, long long T, int W, int stride, int app, double stat2,
+                              const float* x_out, const int8_t* label_out, const float* app_power_out,
+                              const int8_t* app_state_out, const int* count_out, int* n_wins) {
+    if (!series || !x_out || !count_out) return fail(CAMAL_ERR_ARG, "series_dev, x_out and count_out are required");
+    if (n_rows < 1 || T < 1 || W < 1 || stride < 1) return fail(CAMAL_ERR_ARG, "n_rows, T, W and stride must be >= 1");
+    if (app < 1) return fail(CAMAL_ERR_ARG, "app is the 1-based appliance index");
+    if ((label_out || app_power_out || app_state_out) && 2 * app >= n_rows)
+        return fail(CAMAL_ERR_ARG, "the series has no (power, status) rows for that appliance");
+    if (stat2 == 0.0) return fail(CAMAL_ERR_ARG, "stat2 must not be 0");
+    *n_wins = camal_windows_count(T, W, stride);
+    if (*n_wins < 1) return fail(CAMAL_ERR_ARG, "the series is shorter than one window");
+    return 0;
+}
+
+int camal_build_windows(const void* series, int series_is_f64, int n_rows, long long T, int W, int stride, int app,
+                        double stat1, double stat2, float* x_out, double* x64_out, int8_t* label_out, float* app_power_out,
+                        int8_t* app_state_out, int* index_out, int* count_out, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+    int n_wins = 0;
+    if (int r = check_windows_args(series, n_rows, T, W, stride, app, stat2, x_out, label_out, app_power_out, app_state_out,
+                                   count_out, &n_wins)) return r;
+    if (!workspace) return fail(CAMAL_ERR_ARG, "workspace_dev is required");
+    if (workspace_bytes < camal_windows_workspace_bytes(n_wins)) return fail(CAMAL_ERR_ARG, "workspace smaller than camal_windows_workspace_bytes(n_wins)");
+    return build_windows_impl(series, series_is_f64, n_rows, T, W, stride, app, stat1, stat2, x_out, x64_out, label_out,
+                              app_power_out, app_state_out, index_out, count_out, n_wins, workspace, stream);
+}
+
+// ---- the entry point that allocates nothing (include/camal_hip.h: camal_build_windows_static) ----------------
+// Scratch of the window builder (NaN flags, scan positions, block totals) for up to CAMAL_WINDOWS_STATIC_MAX windows,
+// as a file-scope device array: every GPU the library runs on holds its own copy until the process ends.  In host
+// code the array's name is only a handle for hipGetSymbolAddress; kernels get the resolved per-device address.
+constexpr size_t win_ws_bytes(size_t n) {  // = camal_windows_workspace_bytes(n), monotone in n
+    return ((n + 255) & ~(size_t)255) + ((n * 4 + 255) & ~(size_t)255) +
+           (((n + WIN_SCAN_BLOCK - 1) / WIN_SCAN_BLOCK * 4 + 255) & ~(size_t)255);
+}
+constexpr size_t kWinScratchBytes = win_ws_bytes(CAMAL_WINDOWS_STATIC_MAX);  // 5 MiB + 4 KiB
+static __device__ __align__(256) unsigned char g_win_scratch[kWinScratchBytes];
+
+constexpr int kMaxDevices = 64;
+static void* g_win_scratch_ptr[kMaxDevices];  // resolved address of g_win_scratch on each device (0: not yet)
+static std::mutex g_win_scratch_mu;
+
+// address of this device's copy of the scratch array; resolved once per device with that device current
+static int win_scratch_for_current_device(void** out) {
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return fail(CAMAL_ERR_ARG, "device index beyond the static scratch table");
+    std::lock_guard<std::mutex> lock(g_win_scratch_mu);
+    if (!g_win_scratch_ptr[dev]) {
+        void* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(g_win_scratch)));
+        if (!p) return fail(CAMAL_ERR_HIP, "hipGetSymbolAddress returned a null scratch address");
+        g_win_scratch_ptr[dev] = p;
+    }
+    *out = g_win_scratch_ptr[dev];
+    return 0;
+}
+
+size_t camal_windows_static_scratch_bytes(void) { return kWinScratchBytes; }
+
+int camal_build_windows_static(const void* series, int series_is_f64, int n_rows, long long T, int W, int stride, int app,
+                               double stat1, double stat2, float* x_out, double* x64_out, int8_t* label_out,
+                               float* app_power_out, int8_t* app_state_out, int* index_out, int* count_out, void* stream) {
+    int n_wins = 0;
+    if (int r = check_windows_args(series, n_rows, T, W, stride, app, stat2, x_out, label_out, app_power_out, app_state_out,
+                                   count_out, &n_wins)) return r;
+    if (n_wins > CAMAL_WINDOWS_STATIC_MAX)
+        return fail(CAMAL_ERR_ARG, "camal_build_windows_static: " + std::to_string(n_wins) + " windows exceed the static scratch's maximum of " +
+                                       std::to_string(CAMAL_WINDOWS_STATIC_MAX) + " (use camal_build_windows with a caller workspace)");
+    if (camal_windows_workspace_bytes(n_wins) > kWinScratchBytes) return fail(CAMAL_ERR_ARG, "static scratch too small (internal)");
+    void* scratch = nullptr;
+    if (int r = win_scratch_for_current_device(&scratch)) return r;
+    // every scratch byte a call reads (keep[0..n), pos[0..n), block totals[0..nb)) is written by that call's own
+    // kernels first, so the previous call's contents need no clearing
+    return build_windows_impl(series, series_is_f64, n_rows, T, W, stride, app, stat1, stat2, x_out, x64_out, label_out,
+                              app_power_out, app_state_out, index_out, count_out, n_wins, scratch, stream);
 }
 
 static int nilm_blocks(size_t n) {

@@ -176,6 +176,20 @@ int camal_build_windows(const void* series_dev, int series_is_f64, int n_rows, l
                         float* app_power_out, int8_t* app_state_out, int* index_out, int* count_out,
                         void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* The same window builder for callers that cannot allocate or pass a workspace (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference: it exists only for
+ * those callers.  The scratch (NaN flags, scan positions, block totals) lives in a file-scope device array of
+ * camal_windows_static_scratch_bytes() = 5 MiB + 4 KiB that every GPU the library runs on holds until the process
+ * ends; the call runs on the CURRENT device, makes no hipMalloc / hipFree and returns CAMAL_ERR_ARG when the series
+ * yields more than CAMAL_WINDOWS_STATIC_MAX windows.  All calls on one GPU share that array: calls that overlap
+ * on one GPU (two streams, two threads) race — serialise them.  Arguments and results as camal_build_windows. */
+#define CAMAL_WINDOWS_STATIC_MAX (1 << 20)
+size_t camal_windows_static_scratch_bytes(void);
+int camal_build_windows_static(const void* series_dev, int series_is_f64, int n_rows, long long T, int W, int stride,
+                               int app, double stat1, double stat2, float* x_out, double* x64_out, int8_t* label_out,
+                               float* app_power_out, int8_t* app_state_out, int* index_out, int* count_out,
+                               void* stream);
+
 /* ------------------------------- training (one ResNet member) -------------------------------
  * Replaces the per-batch body of BasedClassifTrainer.__train (torch_trainer.py:281-298) for
  * CamALResNet in train() mode: forward with BatchNorm batch statistics (biased variance,
