@@ -292,6 +292,22 @@ struct ProfScope {
 };
 
 // ---- launches -------------------------------------------------------------------------
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: every kernel instantiation keeps its
+// high-water mark per device (table of kAttrDevices entries, one per instantiation, guarded by one mutex)
+constexpr int kAttrDevices = 64;
+std::mutex g_attr_mu;
+int ensure_lds_attr(const void* kern, size_t lds, size_t* table) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kAttrDevices) return fail(CAMAL_ERR_ARG, "device index beyond the attribute table");
+    std::lock_guard<std::mutex> lock(g_attr_mu);
+    if (lds > table[dev]) {
+        HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        table[dev] = lds;
+    }
+    return 0;
+}
+
 // L_out: output rows per window; input rows per window L_in, input row for (t, tap j) = t + j - in_off;
 // zero_row == nullptr: out-of-range rows replicate the edge (forward), else they read zeros (dgrad).
 // NTX != 0 overrides the column tiles per wave (narrower time tile for first-kernel sizes whose halo does not fit)
@@ -303,11 +319,8 @@ int launch_conv_w(camal_ctx* c, int num_cu, size_t lds_per_cu, int cam_row, hipS
     auto kern = conv_kernel<DT, CIN, COUT, G::TN / (32 * G::NG), NWC, RELU, HAS_RES, HEAD>;
     const size_t lds = 2 * (size_t)G::buf_bytes(ks) + (HEAD ? G::HEAD_BYTES : 0);
     if (lds > lds_per_cu) return fail(CAMAL_ERR_ARG, "kernel size too large for the LDS tile");
-    static size_t attr_set = 0;  // per instantiation
-    if (lds > attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = lds;
-    }
+    static size_t attr_set[kAttrDevices] = {0};  // per instantiation and device
+    if (int r = ensure_lds_attr((const void*)kern, lds, attr_set)) return r;
     const int tpw = (L_out + G::TN - 1) / G::TN;
     const long long total = (long long)tpw * BC;
     if (total > 0x7fffffffLL) return fail(CAMAL_ERR_ARG, "too many tiles in one pass");
@@ -358,11 +371,8 @@ int launch_block_w(camal_ctx* c, hipStream_t s, const Layer& l1, const Layer& l2
     using G = BGeom<DT, CIN, NWC>;
     auto kern = block_kernel<DT, CIN, NTB, NWC, 1, HAS_RES, HEAD, VARIANT ? 5 : 7, VARIANT>;
     const size_t lds = block_lds<DT, CIN, NWC, HAS_RES, HEAD>(l1.ks);
-    static size_t attr_set = 0;
-    if (lds > attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = lds;
-    }
+    static size_t attr_set[kAttrDevices] = {0};
+    if (int r = ensure_lds_attr((const void*)kern, lds, attr_set)) return r;
     BlockArgs a;
     a.in = in; a.out = out;
     a.w1 = (const uint4*)l1.wpack; a.w2 = (const uint4*)l2.wpack; a.w3 = (const uint4*)l3.wpack;
@@ -402,11 +412,8 @@ int launch_block1_w(camal_ctx* c, hipStream_t s, const Member& m, const float* x
     using G = Block1Geom<DT, NTB, NWC>;
     auto kern = block1_kernel<DT, NTB, NWC, VARIANT ? 5 : 7, VARIANT>;
     if (m.conv[0].ks != (VARIANT ? 5 : 7) || m.conv[1].ks != 3) return fail(CAMAL_ERR_STATE, "fused block 1: unexpected layer kernel sizes");
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
-        attr_set = true;
-    }
+    static size_t attr_set[kAttrDevices] = {0};
+    if (int r = ensure_lds_attr((const void*)kern, (size_t)G::LDS_BYTES, attr_set)) return r;
     Block1Args a;
     a.x = x; a.out = out;
     a.w2 = (const uint4*)m.conv[0].wpack; a.w3 = (const uint4*)m.conv[1].wpack;

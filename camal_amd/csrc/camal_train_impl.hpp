@@ -96,6 +96,14 @@ int wgrad_splits(const camal_trainer* t, const TLayer& l, int B, int* wps_out) {
     return (B + wps - 1) / wps;
 }
 
+// the split count is not monotone in B (a ragged last batch can need more splits than a full one): the partial
+// buffer is sized for the largest count over every batch size the trainer accepts
+int wgrad_splits_max(const camal_trainer* t, const TLayer& l, int max_batch) {
+    int best = 1, wps;
+    for (int B = 1; B <= max_batch; ++B) best = std::max(best, wgrad_splits(t, l, B, &wps));
+    return best;
+}
+
 // ---- typed launch helpers -------------------------------------------------------------------
 template <int CIN, int COUT, bool HAS_RES>
 int t_conv(camal_trainer* t, hipStream_t s, const float* wpack, const float* bias, int ks, const float* in,
@@ -293,15 +301,13 @@ int camal_trainer_create_arch(int device_id, int kernel_size, int max_batch, int
         const TLayer& l = t->lay.conv[i];
         A(&t->wpack[i], (size_t)l.cout * l.cin * l.ks);
         A(&t->wflip[i], (size_t)l.cout * l.cin * l.ks);
-        int wps;
-        wg_max = std::max(wg_max, (size_t)wgrad_splits(t, l, max_batch, &wps) * l.ks * l.cout * l.cin);
+        wg_max = std::max(wg_max, (size_t)wgrad_splits_max(t, l, max_batch) * l.ks * l.cout * l.cin);
     }
     {
         const TLayer& l = t->lay.res[1];
         A(&t->wpack_res2, (size_t)l.cout * l.cin);
         A(&t->wflip_res2, (size_t)l.cout * l.cin);
-        int wps;
-        wg_max = std::max(wg_max, (size_t)wgrad_splits(t, l, max_batch, &wps) * l.cout * l.cin);
+        wg_max = std::max(wg_max, (size_t)wgrad_splits_max(t, l, max_batch) * l.cout * l.cin);
     }
     t->wg_part_floats = wg_max;
     A(&t->wg_part, wg_max);
@@ -430,8 +436,9 @@ int camal_adamw_step(float* params, const float* grads, float* m, float* v, size
                      float beta2, float eps, float weight_decay, void* stream) {
     if (!params || !grads || !m || !v) return fail(CAMAL_ERR_ARG, "null argument");
     if (step < 1) return fail(CAMAL_ERR_ARG, "step counts from 1");
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    // bias corrections in double like torch's Python arithmetic (1 - 0.999^t cancels in float for small t)
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     hipLaunchKernelGGL(adamw_kernel, dim3(gs_blocks(n, 2048)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, n, lr,
                        beta1, beta2, eps, weight_decay, bc1, bc2s);
     HIP_TRY(hipGetLastError());

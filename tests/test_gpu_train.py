@@ -85,6 +85,33 @@ def test_every_gradient_tensor_vs_oracle(k, B, L, arch):
     eng.close()
 
 
+# ragged last batches on a trainer created for batch_size = 128: the weight-gradient split count is not monotone
+# in B (k = 15: B = 80 needs 80 splits, B = 128 only 64), the partial buffer must cover every B <= max_batch
+@pytest.mark.parametrize("k,Bs", [(15, (80, 96, 128, 65)), (25, (45, 96, 87)), (7, (129, 192, 100))])
+def test_ragged_batches_on_a_full_size_trainer(k, Bs):
+    from camal_amd import synth
+    from camal_amd.trainer import TrainEngine
+    from oracle import torch_train
+    from tests.helpers import model_for
+    L = 36
+    sd0 = weights.make_state_dict(k, seed=17, head_gain=1.0)
+    m = model_for(sd0)
+    m.to("cuda:0")
+    m.load_state_dict(sd0)
+    eng = TrainEngine(m, "cuda:0", 256 if max(Bs) > 128 else 128, L)
+    for B in Bs:
+        x, y = synth.ideal_windows(B, L, seed=B)
+        loss_ref, nc_ref, g_ref, _ = torch_train.loss_and_grads(sd0, x, y)
+        loss, ncorrect = eng.forward_backward(x, y, update_running=False)
+        assert abs(loss.item() - loss_ref) < 1e-4 and int(ncorrect.item()) == nc_ref, B
+        grads = _grads_dict(eng, m)
+        for kk in ("layers.2.layers.0.layers.0.weight", "layers.1.layers.1.layers.0.weight", "layers.1.residual.0.weight",
+                   "layers.0.layers.2.layers.0.weight", "linear.weight"):
+            err = np.abs(grads[kk] - g_ref[kk]).max() / np.abs(g_ref[kk]).max()
+            assert err < 1e-3, (B, kk, err)
+    eng.close()
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_trainer_mirror_vs_reference_history(name):
     from camal_amd.resnet import CamALResNet
