@@ -88,3 +88,32 @@ def predict_loop(list_sd, data, w_ma=5):
     prediction = prediction / len(sds)
     prediction = prediction * np.round(prob_detect)
     return oracle.attention_sigmoid_module(data, prediction, w_ma=w_ma), prob_detect
+
+
+def predict_batched(list_sd, data, w_ma=5, batch=128):
+    """The same algorithm with ONE forward per member over batches of windows instead of a batch-1 forward per
+    (member, window) — BASELINE.md §3's second CPU figure (how much of the loop's time is loop overhead).  The
+    arithmetic per window is predict_loop's; the batched conv may differ from the batch-1 conv in the last bit."""
+    sds = [_t(sd) for sd in list_sd]
+    data = np.asarray(data)
+    prediction = np.zeros_like(data)
+    prob_detect = np.zeros((len(data), 1))
+    with torch.no_grad():
+        for sd in sds:
+            w = sd["linear.weight"].numpy()
+            for s in range(0, len(data), batch):
+                xt = torch.tensor(data[s:s + batch][:, None, :]).float()
+                f = features(sd, xt)
+                probs = F.softmax(F.linear(f.mean(dim=-1), sd["linear.weight"], sd["linear.bias"]), dim=1).numpy()
+                cams = np.einsum("c,ncl->nl", w[1], f.numpy())
+                for i in range(len(cams)):
+                    prob_detect[s + i][0] += probs[i, 1]
+                    if probs[i, 1] > probs[i, 0]:
+                        clip_cam = np.nan_to_num(np.clip(cams[i], a_min=0, a_max=None).astype(np.float32), nan=0.0,
+                                                 neginf=0.0, posinf=0.0)
+                        if clip_cam.max() > 0:
+                            prediction[s + i] += clip_cam / clip_cam.max()
+    prob_detect = prob_detect / len(sds)
+    prediction = prediction / len(sds)
+    prediction = prediction * np.round(prob_detect)
+    return oracle.attention_sigmoid_module(data, prediction, w_ma=w_ma), prob_detect

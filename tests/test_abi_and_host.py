@@ -176,3 +176,21 @@ def test_hand_counted_weight_ring_is_untouched_by_the_compiler(tmp_path):
     text = asm.read_text()
     assert text.count("ASMSTART") > 100 and "v_mfma_f32_16x16x32_bf16" in text
     assert check_ring.check(str(asm)) == []
+
+
+def test_bench_spawns_its_own_ranks_dry_run():
+    """`python bench.py --gpus 2` without a launcher: the parent starts the two ranks as children (before anything
+    touches a GPU) and rank 0's line comes through; --dry-run rehearses that path on CPU with gloo."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d == {"dry_run": True, "n_gpus": 2, "max_rank_seen": 1}
