@@ -53,6 +53,7 @@ SIGNATURES = {
     "camal_trainer_create_arch": (_i, [_i, _i, _i, _i, _i, C.POINTER(_vp)]),
     "camal_trainer_param_count_arch": (_sz, [_i, _i]),
     "camal_trainer_destroy": (_i, [_vp]),
+    "camal_trainer_set_grad_scale": (_i, [_vp, C.c_float]),
     "camal_train_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, C.c_float, _vp, _vp, _vp, _vp, _vp]),
     "camal_adamw_step": (_i, [_vp, _vp, _vp, _vp, _sz, _i, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
     "camal_set_profiling": (_i, [_vp, _i]),

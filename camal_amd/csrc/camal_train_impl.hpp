@@ -54,6 +54,7 @@ TLayout make_layout(int k, int arch = CAMAL_ARCH_CAMAL) {
 
 struct camal_trainer {
     int device = 0, k = 0, maxB = 0, maxL = 0, num_cu = 256;
+    float grad_scale = 1.f;         // camal_trainer_set_grad_scale
     int arch = CAMAL_ARCH_CAMAL;    // CAMAL_ARCH_RESNET: kernels 7/5/3 and zeros outside the window (classifiers/resnet.py)
     bool zpad() const { return arch == CAMAL_ARCH_RESNET; }
     size_t lds_per_cu = 160 * 1024;
@@ -338,6 +339,13 @@ int camal_trainer_destroy(camal_trainer* t) {
     return 0;
 }
 
+int camal_trainer_set_grad_scale(camal_trainer* t, float scale) {
+    if (!t) return fail(CAMAL_ERR_ARG, "null trainer");
+    if (!(scale >= 0.f) || !(scale <= 1e6f)) return fail(CAMAL_ERR_ARG, "grad scale must be finite and >= 0");
+    t->grad_scale = scale;
+    return 0;
+}
+
 int camal_train_fwd_bwd(camal_trainer* t, const float* params, float* running, const float* x, const int* y, int B, int L,
                         float momentum, float* grads, float* logits_out, float* loss_out, int* ncorrect_out, void* stream) {
     if (!t || !params || !x) return fail(CAMAL_ERR_ARG, "null argument");
@@ -386,7 +394,7 @@ int camal_train_fwd_bwd(camal_trainer* t, const float* params, float* running, c
     }
     // head + loss
     hipLaunchKernelGGL(head_loss_kernel, dim3(B), dim3(HEAD_LOSS_THREADS), 0, s, t->act[8], params + Y.wfc, params + Y.bfc,
-                       y ? y : (const int*)t->correct, B, L, t->pooled, t->dpool, t->logits, t->dlogits, t->loss, t->correct);
+                       y ? y : (const int*)t->correct, B, L, t->grad_scale, t->pooled, t->dpool, t->logits, t->dlogits, t->loss, t->correct);
     HIP_TRY(hipGetLastError());
     if (logits_out) HIP_TRY(hipMemcpyAsync(logits_out, t->logits, (size_t)B * 2 * 4, hipMemcpyDeviceToDevice, s));
     if (!grads) return 0;

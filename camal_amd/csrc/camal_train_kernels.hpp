@@ -315,11 +315,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 
 // ---- pooled head + cross-entropy (camal_resnet.py:23, torch_trainer.py:288-296) -------------------
 // One workgroup per window: pooled = mean_t F; logits = W pooled + b; softmax; CE; argmax;
-// dlogits = (p - onehot) / B; dpool = W^T dlogits.
+// dlogits = grad_scale * (p - onehot) / B; dpool = W^T dlogits.  grad_scale: 1, or this rank's share b / B_global of a
+// data-parallel step's batch (every gradient of the backward pass is linear in dlogits).
 #define HEAD_LOSS_THREADS 1024
 __global__ __launch_bounds__(HEAD_LOSS_THREADS) void head_loss_kernel(const float* __restrict__ feat /*[B][L][128]*/,
                                                         const float* __restrict__ wfc, const float* __restrict__ bfc,
-                                                        const int* __restrict__ labels, int B, int L,
+                                                        const int* __restrict__ labels, int B, int L, float grad_scale,
                                                         float* __restrict__ pooled /*[B][128]*/,
                                                         float* __restrict__ dpool /*[B][128]*/,
                                                         float* __restrict__ logits /*[B][2]*/,
@@ -358,7 +359,8 @@ __global__ __launch_bounds__(HEAD_LOSS_THREADS) void head_loss_kernel(const floa
         loss[b] = -((y ? l1 : l0) - m - logf(den));
         correct[b] = ((l1 > l0) ? 1 : 0) == y;
         logits[2 * b] = l0; logits[2 * b + 1] = l1;
-        const float d0 = (p0 - (y == 0 ? 1.f : 0.f)) / (float)B, d1 = (p1 - (y == 1 ? 1.f : 0.f)) / (float)B;
+        const float gs = grad_scale / (float)B;
+        const float d0 = (p0 - (y == 0 ? 1.f : 0.f)) * gs, d1 = (p1 - (y == 1 ? 1.f : 0.f)) * gs;
         dlogits[2 * b] = d0; dlogits[2 * b + 1] = d1;
         sl[2] = d0; sl[3] = d1;
     }

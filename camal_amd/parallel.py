@@ -81,41 +81,149 @@ def merge_member_logs(local: dict, dist=None) -> dict:
     return merged
 
 
-def allreduce_mean_(flat: torch.Tensor, dist=None):
-    """In-place mean over ranks of the flat gradient bucket (one collective per step)."""
+def _active(dist=None):
+    """torch.distributed if a process group of more than one rank is up, else None."""
     if dist is None:
         import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return None
+    return dist
+
+
+def rank_world(dist=None):
+    d = _active(dist)
+    return (d.get_rank(), d.get_world_size()) if d is not None else (0, 1)
+
+
+def _gloo_on_gpu(flat, dist):
+    """CPU-test rehearsals run the "gloo" backend on device tensors (one GPU, several ranks): stage through the
+    host there.  RCCL ("nccl") takes the device tensor as it is."""
+    return flat.is_cuda and dist.get_backend() == "gloo"
+
+
+def batch_shard(n: int, dist=None):
+    """[lo, hi) of a step's n samples that this rank trains on: chunks of ceil(n / world) in rank order, the way
+    nn.DataParallel's scatter cuts a batch (torch_trainer.py:82-90); the last ranks of a short batch get fewer
+    samples or none."""
+    r, w = rank_world(dist)
+    chunk = -(-n // w)
+    lo = min(n, r * chunk)
+    return lo, min(n, lo + chunk)
+
+
+def allreduce_mean_(flat: torch.Tensor, dist=None):
+    """In-place mean over ranks of a flat bucket (one collective)."""
+    d = _active(dist)
+    if d is None:
         return flat
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    flat.div_(dist.get_world_size())
+    allreduce_sum_(flat, d)
+    flat.div_(d.get_world_size())
     return flat
 
 
-class PendingMean:
-    """An in-flight ``allreduce_mean_start``: ``wait()`` makes the current stream wait for the collective (the host
-    does not block on "nccl") and finishes the mean."""
+def allreduce_sum_(flat: torch.Tensor, dist=None):
+    """In-place sum over ranks of the flat gradient bucket: ONE collective per step.  The ranks' gradients arrive
+    already weighted by their share of the batch (camal_trainer_set_grad_scale), so the sum is the gradient of the
+    global mean loss and nothing is divided afterwards."""
+    d = _active(dist)
+    if d is None:
+        return flat
+    if _gloo_on_gpu(flat, d):
+        h = flat.cpu()
+        d.all_reduce(h, op=d.ReduceOp.SUM)
+        flat.copy_(h)
+    else:
+        d.all_reduce(flat, op=d.ReduceOp.SUM)
+    return flat
 
-    def __init__(self, flat, work, world):
-        self.flat, self.work, self.world = flat, work, world
+
+def broadcast_(t: torch.Tensor, src=0, dist=None):
+    """In-place broadcast of rank src's tensor (initial weights, rank 0's BatchNorm running statistics)."""
+    d = _active(dist)
+    if d is None:
+        return t
+    if _gloo_on_gpu(t, d):
+        h = t.cpu()
+        d.broadcast(h, src)
+        t.copy_(h)
+    else:
+        d.broadcast(t, src)
+    return t
+
+
+def broadcast_scalar(v: float, src=0, dist=None, device=None) -> float:
+    """Rank src's value on every rank (control path: the validation loss the scheduler and the early stopper
+    decide on must be the same number everywhere, or the ranks' collectives stop matching)."""
+    d = _active(dist)
+    if d is None:
+        return v
+    dev = device if (device is not None and d.get_backend() != "gloo") else "cpu"
+    t = torch.tensor([float(v)], dtype=torch.float64, device=dev)
+    d.broadcast(t, src)
+    return float(t.item())
+
+
+def broadcast_scalar_int(v: int, src=0, dist=None) -> int:
+    """Rank src's integer on every rank (the shuffle seed of an epoch)."""
+    d = _active(dist)
+    if d is None:
+        return v
+    t = torch.tensor([int(v)], dtype=torch.int64, device="cpu" if d.get_backend() == "gloo" else torch.cuda.current_device())
+    d.broadcast(t, src)
+    return int(t.item())
+
+
+def sum_over_ranks(a: np.ndarray, dist=None, device=None) -> np.ndarray:
+    """Element-wise sum over ranks of a small host array (per-epoch loss / accuracy bookkeeping)."""
+    d = _active(dist)
+    if d is None:
+        return a
+    dev = device if (device is not None and d.get_backend() != "gloo") else "cpu"
+    t = torch.as_tensor(np.asarray(a, np.float64)).to(dev)
+    d.all_reduce(t, op=d.ReduceOp.SUM)
+    return t.cpu().numpy()
+
+
+class PendingMean:
+    """An in-flight all-reduce of a flat bucket: ``wait()`` makes the current stream wait for the collective (the
+    host does not block on "nccl") and, for the mean variant, finishes the division."""
+
+    def __init__(self, flat, work, world, staged=None):
+        self.flat, self.work, self.world, self.staged = flat, work, world, staged
 
     def wait(self):
         if self.work is not None:
             self.work.wait()
-            self.flat.div_(self.world)
+            if self.staged is not None:
+                self.flat.copy_(self.staged)
+                self.staged = None
+            if self.world != 1:
+                self.flat.div_(self.world)
             self.work = None
         return self.flat
 
 
-def allreduce_mean_start(flat: torch.Tensor, dist=None) -> PendingMean:
-    """Start the mean over ranks of a flat gradient bucket without waiting for it: the collective runs on the
-    backend's own stream behind the work already queued on the current one, so the next member's forward and backward
-    overlap it (xGMI all-reduces of 2-4 MB are latency-bound).  Nothing may touch ``flat`` before ``wait()``."""
-    if dist is None:
-        import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+def _start(flat, dist, divide):
+    d = _active(dist)
+    if d is None:
         return PendingMean(flat, None, 1)
-    return PendingMean(flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), dist.get_world_size())
+    world = d.get_world_size() if divide else 1
+    if _gloo_on_gpu(flat, d):
+        h = flat.cpu()
+        return PendingMean(flat, d.all_reduce(h, op=d.ReduceOp.SUM, async_op=True), world, staged=h)
+    return PendingMean(flat, d.all_reduce(flat, op=d.ReduceOp.SUM, async_op=True), world)
+
+
+def allreduce_mean_start(flat: torch.Tensor, dist=None) -> PendingMean:
+    """Start the mean over ranks of a flat bucket without waiting for it: the collective runs on the backend's own
+    stream behind the work already queued on the current one, so the next member's forward and backward overlap it
+    (xGMI all-reduces of 2-4 MB are latency-bound).  Nothing may touch ``flat`` before ``wait()``."""
+    return _start(flat, dist, True)
+
+
+def allreduce_sum_start(flat: torch.Tensor, dist=None) -> PendingMean:
+    """The same for the sum (gradient buckets weighted by the ranks' batch shares: nothing to divide)."""
+    return _start(flat, dist, False)
 
 
 def max_over_ranks(value: float, device=None, dist=None) -> float:

@@ -25,8 +25,10 @@ from .metrics import Classifmetrics
 class TSLoader:
     """Minimal stand-in for ``DataLoader(TSDataset(X, y), batch_size, shuffle)``
     (reference core.py:92-119, torch_dataset.py:197-250): yields ``(ts [b,1,L], labels [b])``
-    NumPy batches; ``shuffle=True`` draws a fresh ``torch.randperm`` per epoch from the global
-    torch RNG, like the reference's loader."""
+    NumPy batches.  ``shuffle=True`` consumes the global torch RNG exactly like ``DataLoader(shuffle=True)``
+    does per epoch (one int64 for the iterator's base seed, one for ``RandomSampler``'s seed, then
+    ``randperm`` from a fresh generator seeded with it), so the batch order under ``torch.manual_seed`` is the
+    reference's.  Under ``torch.distributed`` every rank uses rank 0's seed: the ranks cut the SAME batches."""
 
     def __init__(self, X, y, batch_size=1, shuffle=False):
         X = np.asarray(X)
@@ -41,7 +43,13 @@ class TSLoader:
 
     def __iter__(self):
         n = len(self.samples)
-        order = torch.randperm(n).numpy() if self.shuffle else np.arange(n)
+        if self.shuffle:
+            torch.empty((), dtype=torch.int64).random_()  # _BaseDataLoaderIter's base seed
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())  # RandomSampler.__iter__
+            seed = int(parallel.broadcast_scalar_int(seed))
+            order = torch.randperm(n, generator=torch.Generator().manual_seed(seed)).numpy()
+        else:
+            order = np.arange(n)
         for s in range(0, n, self.batch_size):
             idx = order[s:s + self.batch_size]
             yield self.samples[idx], self.labels[idx]
@@ -93,8 +101,10 @@ class TrainEngine:
 
     BETAS, EPS, BN_MOMENTUM = (0.9, 0.999), 1e-8, 0.1  # torch defaults (AdamW, BatchNorm1d)
 
-    def __init__(self, model, device, max_batch, length):
+    def __init__(self, model, device, max_batch, length, data_parallel=True):
         self.lib = _lib.load()
+        # False: this rank trains the member alone (members spread over ranks, CamAL.train)
+        self.data_parallel = bool(data_parallel)
         d = torch.device(device)
         if d.type != "cuda":
             raise _lib.CamalHipError(f"camal_amd trains on MI355X only (device={device!r}); there is no CPU path.")
@@ -123,6 +133,7 @@ class TrainEngine:
             self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
             self.ncorrect = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.step_count = 0
+        self._grad_scale = 1.0
         self.load_from_model(model)
 
     def close(self):
@@ -144,8 +155,23 @@ class TrainEngine:
         self.params.copy_(torch.from_numpy(flat))
         self.running.copy_(torch.from_numpy(run.astype(np.float32)))
         self.num_batches_tracked = int(model._params[self.bn_prefixes[0] + ".num_batches_tracked"])
+        self.sync_from_rank0()
+
+    def _dp(self):
+        return self.data_parallel and parallel.rank_world()[1] > 1
+
+    def sync_from_rank0(self):
+        """Data-parallel replicas start from ONE model: rank 0's parameters, running statistics and Adam moments
+        (nn.DataParallel replicates device 0's module, torch_trainer.py:89)."""
+        if self._dp():
+            for t in (self.params, self.running, self.m, self.v):
+                parallel.broadcast_(t, 0)
 
     def store_to_model(self, model):
+        if self._dp():
+            # BatchNorm running statistics are per rank during a step; the ones that persist are replica 0's, as
+            # with nn.DataParallel (every forward re-replicates device 0's buffers)
+            parallel.broadcast_(self.running, 0)
         flat = self.params.cpu().numpy()
         run = self.running.cpu().numpy()
         o = 0
@@ -166,6 +192,9 @@ class TrainEngine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _device_ctx(self):
+        return torch.cuda.device(self.device)
+
     def _prep(self, ts, labels):
         x = torch.as_tensor(np.ascontiguousarray(np.asarray(ts, dtype=np.float32))) if not torch.is_tensor(ts) else ts.float()
         if x.dim() == 3:
@@ -177,18 +206,38 @@ class TrainEngine:
             y = y.to(self.device).float().long().to(torch.int32).contiguous()
         return x, y
 
-    def forward_backward(self, ts, labels, update_running=True):
-        """Train-mode forward + backward; fills ``self.grads``.  -> (loss tensor[1], ncorrect tensor[1])"""
+    def forward_backward(self, ts, labels, update_running=True, global_batch=None, loss_out=None, ncorrect_out=None):
+        """Train-mode forward + backward on THIS RANK's samples; fills ``self.grads``.
+        -> (loss tensor[1] = this rank's mean loss, ncorrect tensor[1]).
+
+        Data-parallel (``torch.distributed`` up, ``data_parallel``): the gradients are weighted by this rank's share
+        ``len(ts) / global_batch`` of the step's batch (default: equal shares, 1 / world), so the SUM all-reduce in
+        ``optimizer_step`` yields the gradient of the mean loss over the whole batch; a rank whose shard is empty
+        contributes zeros.  ``loss_out`` / ``ncorrect_out``: one-element device tensors to write into instead of
+        ``self.loss`` / ``self.ncorrect`` (the trainer's per-epoch history: no host sync per batch)."""
+        loss_out = self.loss if loss_out is None else loss_out
+        ncorrect_out = self.ncorrect if ncorrect_out is None else ncorrect_out
+        n = len(ts)
+        world = parallel.rank_world()[1] if self._dp() else 1
+        scale = (n / float(global_batch)) if global_batch else 1.0 / world
+        if n == 0:
+            self.grads.zero_()
+            loss_out.zero_()
+            ncorrect_out.zero_()
+            return loss_out, ncorrect_out
         x, y = self._prep(ts, labels)
         B, L = x.shape
+        if scale != self._grad_scale:
+            _lib.check(self.lib.camal_trainer_set_grad_scale(self._h, float(scale)))
+            self._grad_scale = scale
         with torch.cuda.device(self.device):
             _lib.check(self.lib.camal_train_fwd_bwd(
                 self._h, _lib.ptr(self.params), _lib.ptr(self.running) if update_running else None, _lib.ptr(x),
-                _lib.ptr(y), B, L, self.BN_MOMENTUM, _lib.ptr(self.grads), None, _lib.ptr(self.loss),
-                _lib.ptr(self.ncorrect), self._stream()))
+                _lib.ptr(y), B, L, self.BN_MOMENTUM, _lib.ptr(self.grads), None, _lib.ptr(loss_out),
+                _lib.ptr(ncorrect_out), self._stream()))
         if update_running:
             self.num_batches_tracked += 1
-        return self.loss, self.ncorrect
+        return loss_out, ncorrect_out
 
     def forward_train(self, ts):
         """Train-mode logits (batch statistics), no backward, running stats untouched."""
@@ -200,22 +249,20 @@ class TrainEngine:
                                                     self.BN_MOMENTUM, None, _lib.ptr(logits), None, None, self._stream()))
         return logits
 
-    data_parallel = True  # False: this rank trains the member alone (members spread over ranks, CamAL.train)
-
     def start_grad_allreduce(self):
         """Begin this member's gradient all-reduce and return at once; hand the result to ``optimizer_step(...,
         pending=...)`` later (callers that step several members overlap it with the next member's work)."""
         if not self.data_parallel:
             return parallel.PendingMean(self.grads, None, 1)
-        return parallel.allreduce_mean_start(self.grads)
+        return parallel.allreduce_sum_start(self.grads)
 
     def optimizer_step(self, lr, weight_decay, pending=None):
         if pending is not None:
             pending.wait()
         elif self.data_parallel:
-            parallel.allreduce_mean_(self.grads)  # no-op unless torch.distributed is initialised
+            parallel.allreduce_sum_(self.grads)  # no-op unless torch.distributed is initialised
         self.step_count += 1
-        with torch.cuda.device(self.device):
+        with self._device_ctx():
             _lib.check(self.lib.camal_adamw_step(_lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.m),
                                                  _lib.ptr(self.v), self.n, self.step_count, float(lr), self.BETAS[0],
                                                  self.BETAS[1], self.EPS, float(weight_decay), self._stream()))
@@ -231,7 +278,7 @@ def forward_train(model, x):
     xs = np.asarray(x.cpu() if torch.is_tensor(x) else x, dtype=np.float32)
     if xs.ndim == 3:
         xs = xs[:, 0, :]
-    eng = TrainEngine(model, model.device, xs.shape[0], xs.shape[1])
+    eng = TrainEngine(model, model.device, xs.shape[0], xs.shape[1], data_parallel=False)
     try:
         return eng.forward_train(xs)
     finally:
@@ -267,8 +314,8 @@ class BasedClassifTrainer(object):
 
         self.model.to(self.device)
         length = train_loader.samples.shape[-1]
-        self.engine = TrainEngine(self.model, self.device, train_loader.batch_size, length)
-        self.engine.data_parallel = data_parallel  # not in the reference: see CamAL.member_parallel
+        # data_parallel is not in the reference: see CamAL.member_parallel
+        self.engine = TrainEngine(self.model, self.device, train_loader.batch_size, length, data_parallel=data_parallel)
 
     # ------------------------------------------------------------- train (torch_trainer.py:92-171)
     def train(self, n_epochs=10):
@@ -283,6 +330,10 @@ class BasedClassifTrainer(object):
                 self.accuracy_valid_history.append(valid_accuracy)
             else:
                 valid_loss = train_loss
+            if self.engine._dp():
+                # every rank must take the same scheduler / early-stop / snapshot decisions (their collectives have
+                # to match): all of them act on rank 0's number
+                valid_loss = parallel.broadcast_scalar(valid_loss, 0)
 
             if self.scheduler:
                 self.lr = self.scheduler.step(valid_loss)
@@ -360,13 +411,29 @@ class BasedClassifTrainer(object):
 
     # ------------------------------------------------------------ private loops (:273-325)
     def __train(self):
-        total, losses, corrects = 0, [], []
-        for ts, labels in self.train_loader:
-            loss, ncorrect = self.engine.forward_backward(ts, labels)
-            self.engine.optimizer_step(self.lr, self.weight_decay)
-            total += len(labels)
-            losses.append(loss.item())        # the reference syncs per batch too (:296-297)
-            corrects.append(ncorrect.item())
+        """One epoch (torch_trainer.py:273-300).  The reference reads loss and accuracy back per batch (:296-297);
+        here they land in a per-epoch device buffer and come back once, at the end of the epoch.  Data-parallel:
+        every rank walks the same batches and trains on its ``parallel.batch_shard`` of each."""
+        eng = self.engine
+        n_batches = len(self.train_loader)
+        with torch.cuda.device(eng.device):
+            loss_hist = torch.zeros(n_batches, dtype=torch.float32, device=eng.device)
+            nc_hist = torch.zeros(n_batches, dtype=torch.int32, device=eng.device)
+        share = np.zeros(n_batches)
+        total = 0
+        for i, (ts, labels) in enumerate(self.train_loader):
+            n = len(labels)
+            lo, hi = parallel.batch_shard(n) if eng._dp() else (0, n)
+            eng.forward_backward(ts[lo:hi], labels[lo:hi], global_batch=n, loss_out=loss_hist[i:i + 1],
+                                 ncorrect_out=nc_hist[i:i + 1])
+            eng.optimizer_step(self.lr, self.weight_decay)
+            share[i] = (hi - lo) / n
+            total += n
+        losses = loss_hist.cpu().numpy().astype(np.float64) * share  # this rank's part of each batch's mean loss
+        corrects = nc_hist.cpu().numpy().astype(np.float64)
+        if eng._dp():
+            both = parallel.sum_over_ranks(np.concatenate([losses, corrects]), device=eng.device)
+            losses, corrects = both[:n_batches], both[n_batches:]
         return np.mean(losses), np.sum(corrects) / total
 
     def __evaluate(self):

@@ -215,6 +215,13 @@ int camal_trainer_create_arch(int device_id, int kernel_size, int max_batch, int
 size_t camal_trainer_param_count_arch(int kernel_size, int arch); /* 0 for an unknown arch */
 int camal_trainer_destroy(camal_trainer* t);
 
+/* Data-parallel training (replaces nn.DataParallel, torch_trainer.py:82-90, whose loss is the mean over the
+ * GATHERED batch, :288-291): a rank that holds b of a step's B samples sets scale = b / B; camal_train_fwd_bwd then
+ * writes scale x the gradient of its own mean cross-entropy, so that ONE sum all-reduce of the ranks' flat gradient
+ * buckets is the gradient of the global mean loss, ragged shards included.  loss_dev stays the rank's unscaled mean.
+ * Default 1 (single-GPU training).                                                                              */
+int camal_trainer_set_grad_scale(camal_trainer* t, float scale);
+
 /* One forward(+backward) pass on a batch.
  *   params_dev      flat parameters (read)
  *   bn_running_dev  flat running statistics, updated in place (NULL: not updated)

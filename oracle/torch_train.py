@@ -18,12 +18,15 @@ from camal_amd import weights
 
 
 class FunctionalResNet:
-    def __init__(self, sd):
+    def __init__(self, sd, dtype=torch.float32):
+        """dtype=torch.float64: the same arithmetic without float32 rounding (what both float32 implementations
+        approximate), for tests whose tolerance is close to the rounding noise of small batches."""
+        self.dtype = dtype
         sd = weights.to_numpy_state_dict(sd)
         self.k = weights.kernel_size_of(sd)
         self.arch = weights.arch_of(sd)  # "resnet": classifiers/resnet.py's ResNet, zero "same" padding (:62)
         self.keys = weights.trainable_keys(self.k, arch=self.arch)
-        self.p = {k: torch.tensor(np.array(sd[k]), dtype=torch.float32, requires_grad=k in self.keys)
+        self.p = {k: torch.tensor(np.array(sd[k]), dtype=dtype, requires_grad=k in self.keys)
                   for k in sd if not k.endswith("num_batches_tracked")}
         self.nbt = int(sd["layers.0.layers.0.layers.1.num_batches_tracked"])
 
@@ -89,3 +92,41 @@ def train_steps(sd, batches, lr=1e-3, weight_decay=0.0):
         m.nbt += 1
         losses.append(float(loss.detach()))
     return losses, m.state_dict()
+
+
+def _dp_chunks(n, world):
+    """nn.DataParallel's scatter: chunks of ceil(n / world) in device order (the last may be short or missing)."""
+    chunk = -(-n // world)
+    return [(lo, min(n, lo + chunk)) for lo in range(0, n, chunk)]
+
+
+def dp_train_steps(sd, batches, world, lr=1e-3, weight_decay=0.0, dtype=torch.float32):
+    """The reference's ``all_gpu=True`` step (single-process ``nn.DataParallel``, torch_trainer.py:82-90,281-292)
+    restated on CPU: the batch is cut in ``world`` chunks, every replica runs the train-mode forward on its own chunk
+    (BatchNorm batch statistics per replica), the logits are gathered, ONE mean cross-entropy over the whole batch,
+    backward, AdamW.  Only replica 0's running statistics persist (the others' buffers are copies that die with
+    the step).  -> (losses, [first step's gradients {key: array}], final state dict)."""
+    m = FunctionalResNet(sd, dtype=dtype)
+    opt = torch.optim.AdamW(m.parameters(), lr=lr, weight_decay=weight_decay)
+    run_keys = [k for k in m.p if k.endswith("running_mean") or k.endswith("running_var")]
+    losses, first_grads = [], None
+    for x, y in batches:
+        x = torch.as_tensor(np.asarray(x, np.float32)).to(dtype)
+        labels = torch.as_tensor(np.asarray(y)).float().long()
+        opt.zero_grad()
+        chunks = _dp_chunks(len(x), world)
+        start = {k: m.p[k].clone() for k in run_keys}
+        outs = [None] * len(chunks)
+        for r in reversed(range(len(chunks))):  # replica 0 last: its running-statistics update is the one that stays
+            for k in run_keys:  # a fresh buffer per replica (autograd keeps the ones a forward touched)
+                m.p[k] = start[k].clone()
+            lo, hi = chunks[r]
+            outs[r] = m.forward(x[lo:hi])
+        loss = F.cross_entropy(torch.cat(outs, 0), labels)
+        loss.backward()
+        if first_grads is None:
+            first_grads = {k: m.p[k].grad.numpy().copy() for k in m.keys}
+        opt.step()
+        m.nbt += 1
+        losses.append(float(loss.detach()))
+    return losses, first_grads, m.state_dict()

@@ -194,3 +194,45 @@ def test_bench_spawns_its_own_ranks_dry_run():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d == {"dry_run": True, "n_gpus": 2, "max_rank_seen": 1}
+
+
+def test_tsloader_shuffle_is_dataloaders_order():
+    """TSLoader(shuffle=True) walks the samples in the order DataLoader(TSDataset, shuffle=True) (core.py:109-112)
+    would under the same torch.manual_seed, epoch after epoch."""
+    import numpy as np
+    import torch
+    from torch.utils.data import DataLoader, TensorDataset
+    from camal_amd.trainer import TSLoader
+    n = 37
+    torch.manual_seed(123)
+    dl = DataLoader(TensorDataset(torch.arange(n)), batch_size=8, shuffle=True)
+    ref = [[b[0].tolist() for b in dl] for _ in range(3)]
+    torch.manual_seed(123)
+    ours = TSLoader(np.zeros((n, 5), np.float32), np.arange(n), batch_size=8, shuffle=True)
+    got = [[lab.tolist() for _, lab in ours] for _ in range(3)]
+    assert got == ref
+
+
+def test_reduce_lr_on_plateau_is_torchs():
+    """trainer.ReduceLROnPlateau against torch.optim.lr_scheduler.ReduceLROnPlateau as the reference configures it
+    (torch_trainer.py:63-66: 'min', patience, eps=1e-7) on random loss sequences with plateaus, ties and NaN."""
+    import numpy as np
+    import torch
+    from camal_amd.trainer import ReduceLROnPlateau
+    rng = np.random.default_rng(0)
+    for trial in range(40):
+        patience = int(rng.integers(0, 5))
+        lr0 = float(10.0 ** rng.uniform(-6, -2))
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.AdamW([p], lr=lr0)
+        ref = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, "min", patience=patience, eps=1e-7)
+        ours = ReduceLROnPlateau(lr0, patience=patience, eps=1e-7)
+        losses = np.abs(np.cumsum(rng.normal(-0.02, 0.1, size=60))) + 0.05
+        losses[rng.integers(0, 60, size=12)] = losses[rng.integers(0, 60)]  # exact ties
+        losses = np.round(losses, int(rng.integers(1, 6)))                   # plateaus
+        if trial % 7 == 0:
+            losses[int(rng.integers(5, 50))] = np.nan
+        for i, v in enumerate(losses):
+            ref.step(float(v))
+            got = ours.step(float(v))
+            assert got == opt.param_groups[0]["lr"], (trial, i, got, opt.param_groups[0]["lr"])

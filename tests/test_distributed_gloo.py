@@ -1,5 +1,6 @@
 """CPU, world_size 2, gloo: the N>1 paths (window sharding without collectives, the flat
 gradient-bucket all-reduce, the max-over-ranks timing reduce)."""
+import contextlib
 import os
 import socket
 
@@ -146,3 +147,79 @@ def test_member_owner_round_robin():
     assert [parallel.member_owner(i, 8) for i in range(5)] == [0, 1, 2, 3, 4]
     assert [parallel.member_owner(i, 2) for i in range(5)] == [0, 1, 0, 1, 0]
     assert parallel.merge_member_logs({"a": 1}) == {"a": 1}  # no process group: identity
+
+
+# ---- data-parallel training step: ordering of the asynchronous gradient all-reduce ----------------------------
+class _FakeLib:
+    """Stands in for libcamal_hip.so: records what the flat gradient bucket holds when AdamW is launched."""
+
+    def __init__(self, eng):
+        self.eng, self.seen = eng, []
+
+    def camal_adamw_step(self, params, grads, m, v, n, step, *rest):
+        self.seen.append((int(step), self.eng.grads.clone()))
+        return 0
+
+
+def _fake_engine(n, value):
+    from camal_amd.trainer import TrainEngine
+    e = object.__new__(TrainEngine)  # no GPU, no library: only the buffers the collective path touches
+    e.device, e.data_parallel, e.n, e.step_count = None, True, n, 0
+    e.grads = torch.full((n,), float(value))
+    e.params, e.m, e.v = torch.zeros(n), torch.zeros(n), torch.zeros(n)
+    e.running = torch.zeros(4)
+    e._stream = lambda: None
+    e._device_ctx = contextlib.nullcontext
+    e.lib = _FakeLib(e)
+    return e
+
+
+def _dp_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # three members as bench.py steps them: start every all-reduce, then wait + update member by member
+        engs = [_fake_engine(1000 + i, (rank + 1) * (i + 1)) for i in range(3)]
+        pend = [e.start_grad_allreduce() for e in engs]
+        for e, p in zip(engs, pend):
+            e.optimizer_step(1e-3, 0.0, pending=p)
+        for i, e in enumerate(engs):
+            (step, g), = e.lib.seen
+            want = sum((r + 1) * (i + 1) for r in range(world))  # SUM: the shares already carry the 1 / world
+            assert step == 1 and torch.equal(g, torch.full((1000 + i,), float(want))), (i, g[:3])
+        # without a pending handle optimizer_step reduces by itself; a member-parallel engine reduces nothing
+        e = _fake_engine(10, rank + 1)
+        e.optimizer_step(1e-3, 0.0)
+        assert torch.equal(e.lib.seen[0][1], torch.full((10,), 3.0))
+        e = _fake_engine(10, rank + 1)
+        e.data_parallel = False
+        e.optimizer_step(1e-3, 0.0, pending=e.start_grad_allreduce())
+        assert torch.equal(e.lib.seen[0][1], torch.full((10,), float(rank + 1)))
+        # replicas start from rank 0's buffers, and rank 0's running statistics are the ones that persist
+        e = _fake_engine(10, 0)
+        e.params += rank + 5
+        e.running += rank + 7
+        e.sync_from_rank0()
+        assert torch.equal(e.params, torch.full((10,), 5.0)) and torch.equal(e.running, torch.full((4,), 7.0))
+        # batch shards (nn.DataParallel's scatter), shared shuffle seed, shared decision value
+        assert parallel.batch_shard(13) == ((0, 7) if rank == 0 else (7, 13))
+        assert parallel.batch_shard(1) == ((0, 1) if rank == 0 else (1, 1))
+        from camal_amd.trainer import TSLoader
+        torch.manual_seed(50 + rank)  # different RNG states: the order must still be rank 0's
+        order = [lab.tolist() for _, lab in TSLoader(np.zeros((9, 4)), np.arange(9), batch_size=4, shuffle=True)]
+        torch.manual_seed(50)
+        torch.empty((), dtype=torch.int64).random_()
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        ref = torch.randperm(9, generator=torch.Generator().manual_seed(seed)).tolist()
+        assert sum(order, []) == ref
+        assert parallel.broadcast_scalar(0.25 * (rank + 1)) == 0.25
+        assert np.array_equal(parallel.sum_over_ranks(np.array([1.0, rank])), [2.0, 1.0])
+        open(os.path.join(tmp, f"ok{rank}"), "w").close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_step_ordering(tmp_path):
+    mp.spawn(_dp_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
