@@ -41,10 +41,17 @@ class TSLoader:
     def __len__(self):
         return (len(self.samples) + self.batch_size - 1) // self.batch_size
 
+    @staticmethod
+    def draw_base_seed():
+        """Every DataLoader iterator, shuffling or not, draws one int64 from the global torch RNG when it is created
+        (``_BaseDataLoaderIter``'s base seed): a pass over a loader here consumes the same, so that a run under
+        ``torch.manual_seed`` sees the reference's shuffles epoch after epoch (its validation passes included)."""
+        torch.empty((), dtype=torch.int64).random_()
+
     def __iter__(self):
         n = len(self.samples)
+        self.draw_base_seed()
         if self.shuffle:
-            torch.empty((), dtype=torch.int64).random_()  # _BaseDataLoaderIter's base seed
             seed = int(torch.empty((), dtype=torch.int64).random_().item())  # RandomSampler.__iter__
             seed = int(parallel.broadcast_scalar_int(seed))
             order = torch.randperm(n, generator=torch.Generator().manual_seed(seed)).numpy()
@@ -293,6 +300,19 @@ class BasedClassifTrainer(object):
                  data_parallel=True):
         if criterion is not None or valid_criterion is not None:
             raise NotImplementedError("the HIP training step implements nn.CrossEntropyLoss() (the reference default)")
+        self._init_host(model, train_loader, valid_loader, learning_rate, weight_decay, patience_es, patience_rlr, device,
+                        all_gpu, n_warmup_epochs, f_metrics, verbose, plotloss, save_fig, path_fig, save_checkpoint,
+                        path_checkpoint)
+        self.model.to(self.device)
+        length = train_loader.samples.shape[-1]
+        # data_parallel is not in the reference: see CamAL.member_parallel
+        self.engine = TrainEngine(self.model, self.device, train_loader.batch_size, length, data_parallel=data_parallel)
+
+    def _init_host(self, model, train_loader, valid_loader, learning_rate, weight_decay, patience_es, patience_rlr,
+                   device, all_gpu, n_warmup_epochs, f_metrics, verbose=False, plotloss=False, save_fig=False,
+                   path_fig=None, save_checkpoint=False, path_checkpoint=None):
+        """Everything of torch_trainer.py:33-80 that is host state (no device, no library): the epoch logic of
+        ``train`` runs on it alone, which is how the CPU suite checks it against the reference's decisions."""
         self.model = model
         self.train_loader, self.valid_loader = train_loader, valid_loader
         self.f_metrics, self.device, self.all_gpu = f_metrics, device, all_gpu
@@ -311,11 +331,6 @@ class BasedClassifTrainer(object):
         self.accuracy_train_history, self.accuracy_valid_history = [], []
         if self.patience_es is not None:
             self.early_stopping = EarlyStopper(patience=self.patience_es)
-
-        self.model.to(self.device)
-        length = train_loader.samples.shape[-1]
-        # data_parallel is not in the reference: see CamAL.member_parallel
-        self.engine = TrainEngine(self.model, self.device, train_loader.batch_size, length, data_parallel=data_parallel)
 
     # ------------------------------------------------------------- train (torch_trainer.py:92-171)
     def train(self, n_epochs=10):
@@ -446,6 +461,8 @@ class BasedClassifTrainer(object):
         depend on the batch they were computed in, so the per-batch losses are rebuilt from them."""
         self.engine.store_to_model(self.model)
         self.model.eval()
+        if hasattr(loader, "draw_base_seed"):
+            loader.draw_base_seed()  # the reference iterates the loader here (torch_trainer.py:182,311)
         X = loader.samples[:, 0, :]
         logits = self.model(X.astype(np.float32))
         labels = torch.as_tensor(loader.labels).to(logits.device).float().long()

@@ -203,6 +203,132 @@ def train_case(name, k, seed, n, length, batch, epochs, lr=1e-3, arch=weights.AR
           f"acc={np.round(tr.accuracy_train_history, 3).tolist()} size={os.path.getsize(os.path.join(HERE, name + '.npz')) / 1024:.0f} KB")
 
 
+def big_ensemble_case(name="cfg0_l1024", n=64, length=1024, data_seed=0, seed=107, gain=2.0):
+    """BASELINE configs[0] at full size through the reference's own CamAL.predict (E=5, k=5,7,9,15,25, 64 x 1024
+    UK-DALE-shaped windows, data seed 0): the windows come back from the seed, the states are stored as int8, the
+    per-member CAMs and the averaged CAM at every 8th timestamp."""
+    data = synth.ukdale_windows(n, length, seed=data_seed)
+    gains, biases = calibrate_heads(data, seed, gain)
+    sds = [weights.make_state_dict(k, seed=seed, head_gain=g, head_bias=b) for k, g, b in zip(KERNELS, gains, biases)]
+    cams = np.zeros((len(KERNELS), n, length), np.float32)
+    labels = np.zeros((len(KERNELS), n), np.int32)
+    probs = np.zeros((len(KERNELS), n, 2), np.float32)
+    for e, sd in enumerate(sds):
+        m = ref_model(sd)
+        cam = CAM(model=m, device="cpu", last_conv_layer=m._modules["layers"][2], fc_layer_name=m._modules["linear"])
+        for i in range(n):
+            c, lab, p = cam.run(instance=data[i], returned_cam_for_label=1)
+            cams[e, i], labels[e, i], probs[e, i] = c, lab, p
+    logs = {"ensemble_training_logs": {}, "camal_predictors_id": [], "is_fitted": True}
+    for e, (k, sd) in enumerate(zip(KERNELS, sds)):
+        logs["ensemble_training_logs"][f"Predictor_{e}"] = {"kernel_size": k, "best_model_state_dict": to_torch_sd(sd)}
+        logs["camal_predictors_id"].append(f"Predictor_{e}")
+    camal = CamAL(n_predictors=len(KERNELS), device="cpu")
+    camal.camal_logs, camal.is_fitted = logs, True
+    captured = {}
+    orig_att = camal.attention_sigmoid_module
+
+    def capture(d, soft_label, w_ma=5):
+        captured["avg_cam"] = np.array(soft_label)
+        return orig_att(d, soft_label, w_ma=w_ma)
+
+    camal.attention_sigmoid_module = capture
+    states, prob_detect = camal.predict(data, return_prob=True)
+    assert set(np.unique(states)) <= {0.0, 1.0}
+    np.savez_compressed(
+        os.path.join(HERE, name + ".npz"), members=np.array(KERNELS), seed=np.array(seed), data_seed=np.array(data_seed),
+        n=np.array(n), length=np.array(length), head_gain=np.array(gains, np.float64), head_bias=np.array(biases, np.float64),
+        cam_stride=np.array(8), cams_strided=cams[:, :, ::8], cam_row_max=cams.max(axis=-1), labels=labels, probs=probs,
+        avg_cam_strided=captured["avg_cam"][:, ::8].astype(np.float32), states=states.astype(np.int8), prob_detect=prob_detect)
+    print(f"{name}: N={n} L={length} labels1={labels.mean():.2f} prob_detect in [{prob_detect.min():.3f},{prob_detect.max():.3f}] "
+          f"states_on={float((states != 0).mean()):.3f} min|p-0.5|={np.abs(prob_detect - 0.5).min():.4f} "
+          f"size={os.path.getsize(os.path.join(HERE, name + '.npz')) / 1024:.0f} KB")
+
+
+def trainer_control_flow_case(name="trainer_control_flow"):
+    """BasedClassifTrainer.train's epoch logic (torch_trainer.py:92-171: ReduceLROnPlateau, EarlyStopper after the
+    warm-up, best-loss snapshot) of the REFERENCE on scripted epoch results: its two private epoch methods are
+    replaced by the scripts of tests/helpers.scripted_trainer_scenarios, everything else is its own code."""
+    from src.helpers.torch_trainer import BasedClassifTrainer
+    from tests.helpers import scripted_trainer_scenarios
+    out = {}
+    for i, sc in enumerate(scripted_trainer_scenarios()):
+        model = torch.nn.Linear(2, 2)
+        tr = BasedClassifTrainer(model, train_loader=[], valid_loader=[0] if sc["has_valid"] else None,
+                                 learning_rate=sc["lr"], weight_decay=0, patience_es=sc["patience_es"],
+                                 patience_rlr=sc["patience_rlr"], device="cpu", n_warmup_epochs=sc["n_warmup_epochs"])
+        lrs, calls = [], {"n": -1}
+
+        def fake_train(sc=sc, calls=calls):  # train() runs it exactly once per epoch, first
+            calls["n"] += 1
+            return sc["train_loss"][calls["n"]], sc["train_acc"][calls["n"]]
+
+        def fake_eval(sc=sc, calls=calls):
+            return sc["valid_loss"][calls["n"]], sc["valid_acc"][calls["n"]]
+
+        tr._BasedClassifTrainer__train = fake_train
+        tr._BasedClassifTrainer__evaluate = fake_eval
+        if tr.scheduler is not None:
+            orig = tr.scheduler.step
+
+            def step(v, orig=orig, tr=tr, lrs=lrs):
+                orig(v)
+                lrs.append(tr.optimizer.param_groups[0]["lr"])
+
+            tr.scheduler.step = step
+        tr.train(sc["n_epochs"])
+        out[f"lrs_{i}"] = np.array(lrs, np.float64)
+        out[f"epochs_run_{i}"] = np.array(len(tr.loss_train_history))
+        out[f"passed_epochs_{i}"] = np.array(tr.passed_epochs)
+        out[f"best_loss_{i}"] = np.array(float(tr.best_loss))
+        out[f"epoch_best_{i}"] = np.array(int(tr.log.get("epoch_best_loss", -1)))
+        out[f"value_best_{i}"] = np.array(float(tr.log.get("value_best_loss", np.nan)))
+        out[f"valid_metrics_{i}"] = np.array(float(tr.log.get("valid_metrics", np.nan)))
+        out[f"final_lr_{i}"] = np.array(float(tr.optimizer.param_groups[0]["lr"]))
+        print(f"{name}[{i}]: epochs {sc['n_epochs']} -> ran {len(tr.loss_train_history)}, best epoch {out[f'epoch_best_{i}']}, "
+              f"lr {sc['lr']:g} -> {float(out[f'final_lr_{i}']):g}, es={sc['patience_es']} rlr={sc['patience_rlr']} warm={sc['n_warmup_epochs']} valid={sc['has_valid']}")
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
+def trainer_valid_case(name="trainer_valid_l64", k=7, seed=204, n_train=48, n_valid=24, length=64, batch=16, epochs=14,
+                       lr=5e-3, shuffle_seed=7):
+    """The reference trainer WITH a validation loader (batch size 1, core.py:114-116), shuffle=True, ReduceLROnPlateau
+    (patience 1), early stopping (patience 2) after one warm-up epoch: pins the LR sequence, the stop epoch, the best
+    epoch and the validation histories."""
+    from src.helpers.torch_dataset import TSDataset
+    from src.helpers.torch_trainer import BasedClassifTrainer
+    from tests.helpers import trainer_valid_inputs
+    xt, yt, xv, yv = trainer_valid_inputs(seed, n_train, n_valid, length)
+    sd0 = weights.make_state_dict(k, seed=seed, head_gain=1.0)
+    m = CamALResNet(kernel_size=k)
+    m.load_state_dict(to_torch_sd(sd0))
+    torch.manual_seed(shuffle_seed)
+    tl = torch.utils.data.DataLoader(TSDataset(xt, yt), batch_size=batch, shuffle=True)
+    vl = torch.utils.data.DataLoader(TSDataset(xv, yv), batch_size=1, shuffle=False)
+    tr = BasedClassifTrainer(m, train_loader=tl, valid_loader=vl, learning_rate=lr, weight_decay=0, patience_es=2,
+                             patience_rlr=1, device="cpu", all_gpu=False, n_warmup_epochs=1)
+    lrs = []
+    orig = tr.scheduler.step
+
+    def step(v):
+        orig(v)
+        lrs.append(tr.optimizer.param_groups[0]["lr"])
+
+    tr.scheduler.step = step
+    tr.train(epochs)
+    test_loss, _ = tr.evaluate(vl)
+    np.savez_compressed(
+        os.path.join(HERE, name + ".npz"), k=np.array(k), seed=np.array(seed), n_train=np.array(n_train), n_valid=np.array(n_valid),
+        length=np.array(length), batch=np.array(batch), epochs=np.array(epochs), lr=np.array(lr), shuffle_seed=np.array(shuffle_seed),
+        lrs=np.array(lrs), epochs_run=np.array(len(tr.loss_train_history)), passed_epochs=np.array(tr.passed_epochs),
+        epoch_best_loss=np.array(tr.log["epoch_best_loss"]), value_best_loss=np.array(tr.log["value_best_loss"]),
+        loss_train_history=np.array(tr.loss_train_history), loss_valid_history=np.array(tr.loss_valid_history),
+        accuracy_train_history=np.array(tr.accuracy_train_history), accuracy_valid_history=np.array(tr.accuracy_valid_history),
+        eval_loss=np.array(test_loss))
+    print(f"{name}: ran {len(tr.loss_train_history)}/{epochs} epochs, lrs={lrs}, best epoch {tr.log['epoch_best_loss']} "
+          f"({tr.log['value_best_loss']:.4f})\n  valid={np.round(tr.loss_valid_history, 4).tolist()}\n  train={np.round(tr.loss_train_history, 4).tolist()}")
+
+
 def metrics_case(name="metrics_ref"):
     """NILMmetrics / Classifmetrics of the reference (other.py:86-159, sklearn underneath) on seeded arrays:
     powers with NaN / +-inf entries, states as post_kernel emits them for unsigned inputs (-0, 0, 1), detection scores
@@ -311,6 +437,18 @@ def main():
         return metrics_case()
     if len(sys.argv) > 1 and sys.argv[1] == "windows":
         return windows_case()
+    if len(sys.argv) > 1 and sys.argv[1] == "cfg0":
+        return big_ensemble_case()
+    if len(sys.argv) > 1 and sys.argv[1] == "control":
+        return trainer_control_flow_case()
+    if len(sys.argv) > 1 and sys.argv[1] == "trainvalid":
+        return trainer_valid_case()
+    if len(sys.argv) > 1 and sys.argv[1] == "train510":
+        return train_case("train_k7_l510", k=7, seed=205, n=128, length=510, batch=128, epochs=1)
+    big_ensemble_case()
+    trainer_control_flow_case()
+    trainer_valid_case()
+    train_case("train_k7_l510", k=7, seed=205, n=128, length=510, batch=128, epochs=1)
     windows_case()
     metrics_case()
     resnet_variant_cases()

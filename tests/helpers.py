@@ -75,3 +75,37 @@ def pack_train_views(keys, grads):
                             if np.asarray(grads[k]).size <= 2048 and not is_bn_fed_bias(k)])
     big = np.concatenate([np.asarray(grads[k]).ravel()[::97] for k in keys if np.asarray(grads[k]).size > 2048])
     return norms, small, big
+
+
+# ---- scripted control-flow scenarios of BasedClassifTrainer.train (tests/golden/trainer_control_flow.npz) -------
+def scripted_trainer_scenarios():
+    """Per-epoch (train loss, train acc, valid loss, valid acc) scripts + trainer settings, from fixed seeds: fed to
+    the REFERENCE trainer by make_golden.py (its private epoch methods replaced by the script) and to this repo's
+    trainer by tests/test_abi_and_host.py, so that scheduler / early stop / warm-up / snapshot logic is compared
+    decision by decision without any arithmetic noise in between."""
+    rng = np.random.default_rng(77)
+    out = []
+    for i in range(16):
+        n_epochs = int(rng.integers(6, 25))
+        base = np.abs(np.cumsum(rng.normal(-0.03, 0.08, size=n_epochs))) + 0.1
+        valid = np.round(base + rng.normal(0, 0.02, size=n_epochs), int(rng.integers(2, 5)))
+        if i % 3 == 0:  # a long plateau: LR drops, then early stop
+            valid[n_epochs // 3:] = valid[n_epochs // 3] + 0.01
+        train = np.round(base * 0.9, 4)
+        out.append(dict(
+            n_epochs=n_epochs, train_loss=train, valid_loss=np.abs(valid) + 0.01,
+            train_acc=np.round(rng.uniform(0.5, 1.0, n_epochs), 3), valid_acc=np.round(rng.uniform(0.5, 1.0, n_epochs), 3),
+            has_valid=bool(i % 4 != 3), patience_es=[None, 1, 2, 5][i % 4] if i % 5 else 3,
+            patience_rlr=[None, 0, 1, 3][(i // 2) % 4], n_warmup_epochs=int([0, 1, 2, 4][(i // 3) % 4]),
+            lr=float([1e-3, 3e-3, 1e-4][i % 3])))
+    return out
+
+
+def trainer_valid_inputs(seed, n_train, n_valid, length, flip=0.3):
+    """Windows and labels of the ``trainer_valid_*`` fixture: IDEAL-shaped windows with a share of the labels flipped
+    (so that the validation loss turns upwards and the scheduler / early stopper have something to decide on)."""
+    from camal_amd import synth
+    x, y = synth.ideal_windows(n_train + n_valid, length, seed=seed)
+    noise = np.random.default_rng(seed + 1000).random(len(y)) < flip
+    y = np.where(noise, 1 - y, y)
+    return x[:n_train], y[:n_train], x[n_train:], y[n_train:]

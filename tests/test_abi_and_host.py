@@ -236,3 +236,65 @@ def test_reduce_lr_on_plateau_is_torchs():
             ref.step(float(v))
             got = ours.step(float(v))
             assert got == opt.param_groups[0]["lr"], (trial, i, got, opt.param_groups[0]["lr"])
+
+
+def test_trainer_epoch_logic_equals_the_references_decisions():
+    """tests/golden/trainer_control_flow.npz: what the REFERENCE's BasedClassifTrainer.train (torch_trainer.py:92-171)
+    did on 16 scripted runs (epoch results replaced by scripts, everything else its own code: torch's
+    ReduceLROnPlateau, EarlyStopper after the warm-up, best-loss snapshot).  This repo's trainer gets the same
+    scripts, host state only (no GPU): LR after every epoch, epochs run, best epoch and value must be equal."""
+    import numpy as np
+    from camal_amd.trainer import BasedClassifTrainer
+    from tests.helpers import load_case, scripted_trainer_scenarios
+    ref = load_case("trainer_control_flow")
+
+    class FakeModel:
+        def state_dict(self):
+            return {"w": 1}
+
+    class FakeEngine:
+        def _dp(self):
+            return False
+
+        def store_to_model(self, model):
+            pass
+
+        def optimizer_state_dict(self, lr, wd):
+            return {"lr": lr}
+
+    stops = drops = 0
+    for i, sc in enumerate(scripted_trainer_scenarios()):
+        tr = BasedClassifTrainer.__new__(BasedClassifTrainer)
+        tr._init_host(FakeModel(), [], [0] if sc["has_valid"] else None, sc["lr"], 0, sc["patience_es"], sc["patience_rlr"],
+                      "cpu", False, sc["n_warmup_epochs"], None)
+        tr.engine = FakeEngine()
+        calls = {"n": -1}
+        lrs = []
+
+        def fake_train(sc=sc, calls=calls, tr=tr, lrs=lrs):
+            if calls["n"] >= 0:
+                lrs.append(tr.lr)  # the LR the previous epoch's scheduler step left
+            calls["n"] += 1
+            return sc["train_loss"][calls["n"]], sc["train_acc"][calls["n"]]
+
+        def fake_eval(sc=sc, calls=calls):
+            return sc["valid_loss"][calls["n"]], sc["valid_acc"][calls["n"]]
+
+        tr._BasedClassifTrainer__train = fake_train
+        tr._BasedClassifTrainer__evaluate = fake_eval
+        tr.train(sc["n_epochs"])
+        lrs.append(tr.lr)
+        if sc["patience_rlr"] is not None:
+            assert np.array_equal(np.array(lrs), ref[f"lrs_{i}"]), (i, lrs, ref[f"lrs_{i}"])
+        assert tr.lr == float(ref[f"final_lr_{i}"]), i
+        assert len(tr.loss_train_history) == int(ref[f"epochs_run_{i}"]), i
+        assert tr.passed_epochs == int(ref[f"passed_epochs_{i}"]), i
+        assert tr.best_loss == float(ref[f"best_loss_{i}"]), i
+        assert tr.log.get("epoch_best_loss", -1) == int(ref[f"epoch_best_{i}"]), i
+        if int(ref[f"epoch_best_{i}"]) >= 0:
+            assert tr.log["value_best_loss"] == float(ref[f"value_best_{i}"]), i
+            assert tr.log["valid_metrics"] == float(ref[f"valid_metrics_{i}"]), i
+        assert {"training_time", "loss_train_history", "loss_valid_history"} <= set(tr.log)
+        stops += len(tr.loss_train_history) < sc["n_epochs"]
+        drops += tr.lr < sc["lr"]
+    assert stops >= 5 and drops >= 8  # the scripts do exercise early stops and LR drops

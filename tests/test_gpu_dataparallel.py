@@ -134,6 +134,7 @@ def test_two_processes_run_the_trainer_data_parallel(tmp_path):
         seed = int(torch.empty((), dtype=torch.int64).random_().item())
         order = torch.randperm(n, generator=torch.Generator().manual_seed(seed)).numpy()
         batches += [(x[order[s:s + bs]], y[order[s:s + bs]]) for s in range(0, n, bs)]
+        torch.empty((), dtype=torch.int64).random_()  # the epoch's validation pass creates a loader iterator too
     sd0 = weights.make_state_dict(k, seed=40, head_gain=1.0)
     losses, _, sd_ref = torch_train.dp_train_steps(sd0, batches, world=world, lr=1e-3)
     per_epoch = np.array(losses).reshape(epochs, -1).mean(axis=1)

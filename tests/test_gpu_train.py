@@ -163,3 +163,43 @@ def test_camal_train_end_to_end(tmp_path):
     s2 = fresh.predict(x[80:])
     assert np.array_equal(states, s2)
     assert pickle.load(open(path, "rb"))["training_time"] >= 0
+
+
+def test_trainer_with_validation_vs_reference():
+    """tests/golden/trainer_valid_l64.npz: the reference's BasedClassifTrainer with a batch-1 validation loader,
+    shuffle=True, ReduceLROnPlateau(patience 1), early stopping (patience 2) after one warm-up epoch
+    (torch_trainer.py:92-171).  Same shuffled batches (torch RNG), same LR sequence, same stop and best epochs;
+    histories within 2e-2 relative (six epochs of AdamW at lr 5e-3 amplify float32 rounding differences)."""
+    import torch
+    from camal_amd.trainer import BasedClassifTrainer, TSLoader
+    from tests.helpers import model_for, trainer_valid_inputs
+    c = load_case("trainer_valid_l64")
+    k, seed = int(c["k"]), int(c["seed"])
+    xt, yt, xv, yv = trainer_valid_inputs(seed, int(c["n_train"]), int(c["n_valid"]), int(c["length"]))
+    sd0 = weights.make_state_dict(k, seed=seed, head_gain=1.0)
+    m = model_for(sd0)
+    m.load_state_dict(sd0)
+    torch.manual_seed(int(c["shuffle_seed"]))
+    tr = BasedClassifTrainer(m, train_loader=TSLoader(xt, yt, batch_size=int(c["batch"]), shuffle=True),
+                             valid_loader=TSLoader(xv, yv, batch_size=1), learning_rate=float(c["lr"]), weight_decay=0,
+                             patience_es=2, patience_rlr=1, device="cuda:0", n_warmup_epochs=1)
+    lrs = []
+    orig = tr.scheduler.step
+
+    def step(v):
+        lrs.append(orig(v))
+        return lrs[-1]
+
+    tr.scheduler.step = step
+    tr.train(int(c["epochs"]))
+    assert len(tr.loss_train_history) == int(c["epochs_run"]) < int(c["epochs"])  # stopped early, at the same epoch
+    assert np.array_equal(np.array(lrs), c["lrs"]) and lrs[-1] < lrs[0]            # the LR drop at the same epoch
+    assert tr.passed_epochs == int(c["passed_epochs"])
+    assert tr.log["epoch_best_loss"] == int(c["epoch_best_loss"])
+    # the first (warm-up) validation loss is a batch-statistics artefact of ~50: compare relative to each value
+    assert np.allclose(tr.loss_valid_history, c["loss_valid_history"], rtol=2e-2), (tr.loss_valid_history, c["loss_valid_history"])
+    assert np.allclose(tr.loss_train_history, c["loss_train_history"], rtol=2e-2)
+    assert np.allclose(tr.accuracy_valid_history, c["accuracy_valid_history"], atol=1.5 / len(yv))
+    assert abs(tr.log["value_best_loss"] - float(c["value_best_loss"])) < 2e-2 * float(c["value_best_loss"])
+    loss, _ = tr.evaluate(TSLoader(xv, yv, batch_size=1))
+    assert abs(loss - float(c["eval_loss"])) < 2e-2 * float(c["eval_loss"])

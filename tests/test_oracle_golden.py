@@ -150,3 +150,30 @@ def test_window_oracle_and_scaler_mirror_match_the_reference_fixture():
         assert float(np.abs(sc.inverse_transform(Xs)[:, 0, 0, :] - X[:, 0, 0, :]).max()) == float(c[f"inv_err_{seed}"])
     with pytest.raises(AssertionError):  # the reference's default constructor fails its own assert (:37-38)
         NILMscaler()
+
+
+def test_cfg0_full_size_matches_reference():
+    """BASELINE configs[0] at its own size (E=5, 64 x 1024; tests/golden/cfg0_l1024.npz = the reference's CAM.run
+    and CamAL.predict): the torch restatement on all 64 windows (it is also the CPU baseline bench.py times), the
+    NumPy oracle on every 6th window."""
+    from camal_amd import synth
+    from oracle import torch_path
+    c = load_case("cfg0_l1024")
+    sds = case_state_dicts(c)
+    x = synth.ukdale_windows(int(c["n"]), int(c["length"]), seed=int(c["data_seed"]))
+    states, prob = torch_path.predict_loop(sds, x)
+    assert np.abs(prob - c["prob_detect"]).max() < 1e-6
+    assert (states == c["states"]).mean() >= 0.9999 and set(np.unique(states)) <= {0.0, 1.0}
+    sb, pb = torch_path.predict_batched(sds, x)  # the batched variant of the baseline: same states
+    assert np.abs(pb - c["prob_detect"]).max() < 1e-5 and (sb == c["states"]).mean() >= 0.999
+    idx = np.arange(0, len(x), 6)
+    s2, p2, avg, outs = oracle.camal_predict(sds, x[idx], return_intermediate=True)
+    st = int(c["cam_stride"])
+    assert np.abs(p2 - c["prob_detect"][idx]).max() < REL_TOL_FP32
+    safe = np.abs(c["prob_detect"][idx, 0] - 0.5) > 2e-3
+    assert (s2[safe] == c["states"][idx][safe]).mean() >= 0.999
+    assert np.abs(avg[safe][:, ::st] - c["avg_cam_strided"][idx][safe]).max() < REL_TOL_FP32
+    for e in range(len(sds)):
+        cams, labels, probs = outs[e]
+        assert np.abs(cams[:, ::st] - c["cams_strided"][e][idx]).max() < REL_TOL_FP32 * np.abs(c["cam_row_max"][e][idx]).max()
+        assert np.abs(probs - c["probs"][e][idx]).max() < REL_TOL_FP32
