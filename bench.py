@@ -175,7 +175,7 @@ def run_inference(name, wl, steps, warmup, R, args, min_seconds=0.0, with_cpu_in
             "roofline_post": {
                 "bound": "hbm", "achieved": post_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": post_gbs / HBM_PEAK_GBS, "traffic": measured_traffic(name, "post"),
-                "kernel": "camal::post_kernel (ensemble average + vote gate + moving average + states + power)",
+                "kernel": "camal::post_stream_kernel (ensemble average + vote gate + moving average + states + power; post_kernel for the cases it does not take)",
                 "launches": prof["post"][0], "avg_launch_ms": prof["post"][1] / max(prof["post"][0], 1),
                 "alg_bytes_per_launch": post_bytes_step * steps / max(prof["post"][0], 1),
             },
@@ -184,6 +184,21 @@ def run_inference(name, wl, steps, warmup, R, args, min_seconds=0.0, with_cpu_in
         }
         if wl["precision"] == "bf16":
             res["sanity"]["bf16_vs_fp32"] = bf16_agreement(sds, x, out, dev)
+        # the same box's plain streaming kernels (tools/hbm_probe.hip) as denominators beside the 8 TB/s spec:
+        # a 1 GiB float4 copy (nothing cached), and the post kernel's own read/write mix at its own size in
+        # back-to-back launches (the Infinity Cache holds those buffers: an upper bound the pipeline cannot see,
+        # its CAM rows were written tens of milliseconds of HBM traffic earlier)
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import hbm_probe
+            nr = max(1, int(round(len(ks) * vote_frac)) + 1)
+            copy = hbm_probe.probe(1 << 28, 1, 1, device=dev, blocks=(4096, 16384), reps=5)
+            mix = hbm_probe.probe(B * L, min(nr, 6), 2, device=dev, blocks=(4096,), reps=10)
+            rp = res["roofline_post"]
+            rp["copy_gbs"], rp["same_mix_cached_gbs"] = copy, mix
+            rp["frac_of_copy"] = post_gbs / copy if copy else None
+        except Exception as e:  # noqa: BLE001 — a measurement extra, never fatal
+            res["roofline_post"]["copy_gbs"] = f"probe failed: {e}"
     ens.close()
     del ens, out, x
     torch.cuda.empty_cache()

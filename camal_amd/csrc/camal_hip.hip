@@ -515,9 +515,37 @@ int check_ctx(camal_ctx* c, int B, int L) {
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// post_stream_kernel for E members (1..8) and a 5-step moving average (the reference's default, core.py:257)
+template <bool F64>
+bool launch_post_stream(hipStream_t s, const PostArgs& a, int blocks) {
+    const int segs = (a.L + POST_SEG - 1) / POST_SEG;
+    const long long total = (long long)segs * a.B;
+    if (total > 0x7fffffffLL) return false;
+    const int grid = (int)std::min<long long>((total + 3) / 4, blocks);
+    switch (a.E) {
+#define CAMAL_PS_CASE(NE) case NE: hipLaunchKernelGGL((post_stream_kernel<NE, F64, 5>), dim3(grid), dim3(256), 0, s, a, segs, (int)total); return true;
+        CAMAL_PS_CASE(1) CAMAL_PS_CASE(2) CAMAL_PS_CASE(3) CAMAL_PS_CASE(4)
+        CAMAL_PS_CASE(5) CAMAL_PS_CASE(6) CAMAL_PS_CASE(7) CAMAL_PS_CASE(8)
+#undef CAMAL_PS_CASE
+    }
+    return false;
+}
+
 // own_max: no header_kernel ran; the kernel derives the votes and scans the rows for their maxima
 int launch_post(camal_ctx* c, hipStream_t s, const PostArgs& a0, bool own_max) {
     ProfScope ps(c, s, 3);
+    // the common case goes to the streaming kernel (wave-per-segment, no LDS): same arithmetic, bit-identical
+    static const int stream_mode = getenv("CAMAL_POST_STREAM") ? atoi(getenv("CAMAL_POST_STREAM")) : 1;
+    static const int stream_blocks = getenv("CAMAL_POST_STREAM_BLOCKS") ? atoi(getenv("CAMAL_POST_STREAM_BLOCKS")) : 0;
+    if (stream_mode && !own_max && a0.hdr && !a0.x64 && !a0.avg_out && a0.w_ma == 5 && a0.L % 4 == 0 && a0.E <= 8 &&
+        aligned16(a0.cam) && a0.cam_estride % 4 == 0 && aligned16(a0.x) && aligned16(a0.state_out) && aligned16(a0.power_out)) {
+        const int blocks = stream_blocks > 0 ? stream_blocks : (c ? c->num_cu : 256) * 16;  // measured flat from 12 to 64 per CU
+        const bool ok = a0.pred_f64 ? launch_post_stream<true>(s, a0, blocks) : launch_post_stream<false>(s, a0, blocks);
+        if (ok) {
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
+    }
     const int tiles = (a0.L + POST_TILE - 1) / POST_TILE;
     constexpr int kMaxY = 32768;  // grid.y limit is 65535
     // 16-byte accesses when every row of every array starts on a 16-byte boundary

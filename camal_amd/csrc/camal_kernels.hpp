@@ -1648,6 +1648,97 @@ __global__ __launch_bounds__(POST_THREADS) void post_kernel(PostArgs a) {
     }
 }
 
+// ---- streaming variant of post_kernel for the common case ---------------------------------------------------------
+// (camal_localize with header_kernel's window headers, L % 4 == 0, float32 aggregate, moving-average window W <= 9,
+// no averaged-CAM output).  Same arithmetic, statement for statement, as post_kernel (bit-identical results); what
+// changes is the shape of the memory stream: a WAVE is the unit of work, not a workgroup.  A wave takes one segment of
+// POST_SEG = 62 x 4 timesteps of one window; lanes 1..62 own 4 consecutive timesteps each (one 16-byte access per
+// row), lanes 0 and 63 compute the 4 positions before / after the segment only to feed the moving average, which
+// reaches its neighbours through lane shuffles: no LDS, no barrier, no halo round, every load of an item in flight at
+// once, and a grid-stride loop instead of one small workgroup per tile.
+#define POST_SEG_LANES 62
+#define POST_SEG (POST_SEG_LANES * 4)
+
+template <int NE, bool F64, int W>
+__global__ __launch_bounds__(256) void post_stream_kernel(PostArgs a, int segs_per_window, int total_items) {
+    constexpr int HI = (W - 1) / 2, LO = HI - W + 1;  // np.convolve(..., 'same'): m in [t + LO, t + HI]
+    static_assert(LO >= -4 && HI <= 4, "one neighbour lane on each side covers the window");
+    const int lane = threadIdx.x & 63;
+    const int L = a.L;
+    const int nwaves = gridDim.x * 4;
+    const double inv_w = 1.0 / (double)W, inv_e = 1.0 / (double)NE;
+    for (int item0 = blockIdx.x * 4 + (threadIdx.x >> 6); item0 < total_items; item0 += nwaves) {
+        const int item = __builtin_amdgcn_readfirstlane(item0);
+        const int b = item / segs_per_window, seg = item - b * segs_per_window;
+        const int t0 = seg * POST_SEG + (lane - 1) * 4;
+        const bool inrow = t0 >= 0 && t0 < L;  // L % 4 == 0: a lane's four timesteps are in or out together
+        const bool owner = inrow && lane >= 1 && lane <= POST_SEG_LANES;
+        const size_t row = (size_t)b * L;
+        const unsigned off = 4u * (unsigned)min(max(t0, 0), L - 4);
+        const double* h = a.hdr + (size_t)b * (NE + 1);  // wave-uniform
+        const double vote = h[0];
+        const float4 xv4 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.x + row) + off);
+        double pr[4] = {0.0, 0.0, 0.0, 0.0};
+        if (vote != 0.0) {
+            double ri[NE];
+            float4 v[NE];
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                ri[e] = h[1 + e];
+                v[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ri[e] != 0.0)  // wave-uniform: a member that adds nothing is not read
+                    v[e] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.cam + e * a.cam_estride + row) + off);
+            }
+            float accf[4] = {0.f, 0.f, 0.f, 0.f};
+            double accd[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                if (ri[e] == 0.0) continue;
+                const float c[4] = {v[e].x, v[e].y, v[e].z, v[e].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float q = (float)((double)clip_cam(c[j]) * ri[e]);
+                    if (F64) accd[j] += (double)q;
+                    else accf[j] += q;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double avg = F64 ? accd[j] / (double)NE : (double)(float)((double)accf[j] * inv_e);
+                pr[j] = inrow ? avg * vote : 0.0;
+            }
+        }
+        // p[0..3] = the previous lane's four predictions, p[4..7] = this lane's, p[8..11] = the next lane's
+        double p[12];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            p[4 + j] = pr[j];
+            p[j] = -LO > 3 - j ? __shfl_up(pr[j], 1, 64) : 0.0;
+            p[8 + j] = HI > j ? __shfl_down(pr[j], 1, 64) : 0.0;
+        }
+        const float xs[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
+        float st4[4], pw4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double sum = 0.0;
+#pragma unroll
+            for (int m = LO; m <= HI; ++m) sum += p[4 + j + m];
+            const double xv = (double)xs[j];
+            const double st = attention_state(sum, W, inv_w, xv);
+            st4[j] = (float)st;
+            const double agg = xv * a.scale_mul + a.scale_add;
+            double yh = (double)(int)st * a.p_on;  // astype(int) of -1, -0, 0, 1
+            if (yh > agg) yh = agg;
+            pw4[j] = (float)yh;
+        }
+        if (owner) {
+            const size_t o = row + t0;
+            *reinterpret_cast<float4*>(a.state_out + o) = make_float4(st4[0], st4[1], st4[2], st4[3]);
+            if (a.power_out) *reinterpret_cast<float4*>(a.power_out + o) = make_float4(pw4[0], pw4[1], pw4[2], pw4[3]);
+        }
+    }
+}
+
 // Standalone attention_sigmoid_module (core.py:415-437) on an already averaged soft label:
 // ma = convolve(soft, ones(w), 'same')/w ; s = 2/(1+exp(-ma*x))-1 ; round half to even.
 __global__ __launch_bounds__(256) void attention_kernel(const double* __restrict__ soft, const double* __restrict__ x,
