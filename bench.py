@@ -199,10 +199,30 @@ def run_inference(name, wl, steps, warmup, R, args, min_seconds=0.0, with_cpu_in
             rp["frac_of_copy"] = post_gbs / copy if copy else None
         except Exception as e:  # noqa: BLE001 — a measurement extra, never fatal
             res["roofline_post"]["copy_gbs"] = f"probe failed: {e}"
+    if R.rank == 0 and name == "ensemble_bf16" and R.world == 1:
+        res["host_to_host"] = host_to_host(ens, wl)
     ens.close()
     del ens, out, x
     torch.cuda.empty_cache()
     return res
+
+
+def host_to_host(ens, wl, n_chunks=6):
+    """End to end as CamAL.predict's callers see it: NumPy float32 windows in host memory in, float64 states +
+    probabilities + power in host memory out, through Ensemble.localize_host (chunks through pinned buffers, H2D /
+    D2H on their own streams under the kernels).  Not `value` (that is HBM-resident); one warm-up, one timed pass."""
+    import numpy as np
+    L = wl["L"]
+    chunk = ens.stream_chunk_windows(L)
+    N = n_chunks * chunk + 7
+    x = np.tile(make_windows(wl["shape"], chunk, L, seed=5), (n_chunks + 1, 1))[:N]
+    ens.localize_host(x[:chunk + 1], p_on=2000.0, scale_mul=1000.0)  # pins the buffers
+    t0 = time.perf_counter()
+    states, prob, power = ens.localize_host(x, p_on=2000.0, scale_mul=1000.0)
+    dt = time.perf_counter() - t0
+    return {"value": N / dt, "unit": "windows/s", "windows": N, "chunk_windows": chunk, "seconds": dt,
+            "pcie_bytes_per_window": 4 * L + 16 * L + 8,
+            "what": "NumPy float32 in -> float64 states, float64 power, probabilities out (host memory both sides)"}
 
 
 def bf16_agreement(sds, x, out16, dev, n=512):

@@ -94,6 +94,7 @@ class CamAL(object):
         # knobs that do not exist in the reference
         self.precision = "fp32"   # "bf16": bf16 MFMA convs with fp32 accumulation
         self.prefilter = False    # True: reference device!='cpu' gating (core.py:292-300)
+        self.stream_windows = None  # windows per chunk of predict's host pipeline (None: about 6 M timesteps)
         # True under torch.distributed with world > 1: train() spreads the (kernel size, try) candidates over the
         # ranks (they are independent, core.py:104-158), each trained whole on one GPU with no gradient exchange;
         # the logs are gathered once at the end.  False: every rank trains every candidate data-parallel.
@@ -249,14 +250,15 @@ class CamAL(object):
         if self.list_resnet_predictors is None:
             self.eval()
 
-        res = self._localize_device(data, y=y, w_ma=w_ma, p_on=p_on, scale_mul=scale_mul, scale_add=scale_add)
-        prediction = res["state"].cpu().numpy().astype(np.float64)
-        prob_detect = res["prob"].cpu().numpy().reshape(-1, 1)
+        # NumPy in, NumPy out (core.py:329-332): chunks through pinned buffers, copies under the kernels
+        prediction, prob, power = self._ensemble.localize_host(
+            data, y=y, w_ma=w_ma, gate_mode=int(bool(self.prefilter)), p_on=p_on, scale_mul=scale_mul,
+            scale_add=scale_add, chunk_windows=self.stream_windows)
         out = [prediction]
         if return_prob:
-            out.append(prob_detect)
+            out.append(prob.reshape(-1, 1))
         if p_on is not None:
-            out.append(res["power"].cpu().numpy().astype(np.float64))
+            out.append(power)
         return out[0] if len(out) == 1 else tuple(out)
 
     def _localize_device(self, data, y=None, w_ma=5, p_on=None, scale_mul=1.0, scale_add=0.0):

@@ -164,6 +164,122 @@ class Ensemble:
             res["member_logits"], res["member_cam"] = mlog, mcam
         return res
 
+    # --- NumPy in / NumPy out for N >> what stays resident: chunks through pinned buffers, three streams ---------
+    def stream_chunk_windows(self, L):
+        """Windows per chunk of ``localize_host`` when the caller does not say: about 6 M timesteps (4096 day
+        windows, 585 week windows): a chunk's kernels run for tens of milliseconds, its copies for well under one."""
+        return max(64, min(8192, (6 << 20) // max(int(L), 1)))
+
+    def _host_pipeline(self, chunk, L, is64, want_power):
+        """Two sets of pinned host / device buffers for ``localize_host``, kept for the next call of the same shape
+        (pinning memory costs more than a chunk's work)."""
+        key = (chunk, L, bool(is64), bool(want_power))
+        if getattr(self, "_pipe_key", None) == key:
+            return self._pipe
+        dev = self.device
+        sets = []
+        with torch.cuda.device(dev):
+            for _ in range(2):
+                b = {"in32": torch.empty((chunk, L), dtype=torch.float32).pin_memory(),
+                     "d_in32": torch.empty((chunk, L), dtype=torch.float32, device=dev),
+                     "d_state": torch.empty((chunk, L), dtype=torch.float32, device=dev),
+                     "d_state64": torch.empty((chunk, L), dtype=torch.float64, device=dev),
+                     "d_prob": torch.empty((chunk,), dtype=torch.float64, device=dev),
+                     "state64": torch.empty((chunk, L), dtype=torch.float64).pin_memory(),
+                     "prob": torch.empty((chunk,), dtype=torch.float64).pin_memory(),
+                     "h2d": torch.cuda.Event(), "comp": torch.cuda.Event(), "d2h": torch.cuda.Event(), "n": 0, "s": 0}
+                if is64:
+                    b["in64"] = torch.empty((chunk, L), dtype=torch.float64).pin_memory()
+                    b["d_in64"] = torch.empty((chunk, L), dtype=torch.float64, device=dev)
+                if want_power:
+                    b["d_power"] = torch.empty((chunk, L), dtype=torch.float32, device=dev)
+                    b["d_power64"] = torch.empty((chunk, L), dtype=torch.float64, device=dev)
+                    b["power64"] = torch.empty((chunk, L), dtype=torch.float64).pin_memory()
+                sets.append(b)
+            streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        self._pipe_key, self._pipe = key, (sets, streams)
+        return self._pipe
+
+    def localize_host(self, data, y=None, w_ma=5, gate_mode=0, p_on=None, scale_mul=1.0, scale_add=0.0, chunk_windows=None):
+        """``localize`` for host arrays of any length: ``data`` [N,L] NumPy (float32, or anything else = the float64
+        path of the reference, core.py:286) -> (states [N,L] float64, prob [N] float64, power [N,L] float64 or None)
+        as NumPy arrays.  The windows go through the device in chunks: chunk i+1's host-to-device copy and chunk
+        i-1's device-to-host copy run on their own streams under chunk i's kernels, through pinned buffers, so that
+        the device holds two chunks, not N windows (configs[2]: 10 M day windows).  Same numbers as one call of
+        ``localize`` on everything: windows are independent."""
+        data = np.asarray(data)
+        N, L = data.shape
+        is64 = data.dtype != np.float32
+        want_power = p_on is not None
+        chunk = int(chunk_windows or self.stream_chunk_windows(L))
+        chunk = max(1, min(chunk, N))
+        sets, (s_h2d, s_comp, s_d2h) = self._host_pipeline(chunk, L, is64, want_power)
+        states = np.empty((N, L), dtype=np.float64)
+        prob = np.empty((N,), dtype=np.float64)
+        power = np.empty((N, L), dtype=np.float64) if want_power else None
+        if y is not None:
+            y = np.asarray(y).astype(np.int8).ravel()
+            if y.size != N:
+                raise ValueError("y must hold one label per window")
+
+        def collect(b):  # chunk whose results sit (or will sit) in the pinned buffers of set b -> the output arrays
+            if b["n"] == 0:
+                return
+            b["d2h"].synchronize()
+            s, n = b["s"], b["n"]
+            states[s:s + n] = b["state64"][:n].numpy()
+            prob[s:s + n] = b["prob"][:n].numpy()
+            if want_power:
+                power[s:s + n] = b["power64"][:n].numpy()
+            b["n"] = 0
+
+        cur = torch.cuda.current_stream(self.device)
+        for b in sets:
+            b["n"] = 0
+        with torch.cuda.device(self.device):
+            s_h2d.wait_stream(cur)
+            s_comp.wait_stream(cur)
+            for i, s in enumerate(range(0, N, chunk)):
+                n = min(chunk, N - s)
+                b = sets[i % 2]
+                collect(b)  # the chunk that used this set two steps ago: its copies have landed, buffers are free
+                # host: stage the chunk in pinned memory (the float32 model input; the float64 original beside it)
+                b["in32"][:n].numpy()[...] = data[s:s + n]
+                if is64:
+                    b["in64"][:n].numpy()[...] = data[s:s + n]
+                with torch.cuda.stream(s_h2d):
+                    s_h2d.wait_event(b["comp"])  # the kernels of chunk i-2 have read the device inputs
+                    b["d_in32"][:n].copy_(b["in32"][:n], non_blocking=True)
+                    if is64:
+                        b["d_in64"][:n].copy_(b["in64"][:n], non_blocking=True)
+                    b["h2d"].record(s_h2d)
+                with torch.cuda.stream(s_comp):
+                    s_comp.wait_event(b["h2d"])
+                    s_comp.wait_event(b["d2h"])  # chunk i-2's results have left the device outputs
+                    out = {"prob": b["d_prob"][:n], "state": b["d_state"][:n]}
+                    if want_power:
+                        out["power"] = b["d_power"][:n]
+                    self.localize(b["d_in32"][:n], x64=b["d_in64"][:n] if is64 else None,
+                                  y=None if y is None else y[s:s + n], w_ma=w_ma, gate_mode=gate_mode, pred_f64=is64,
+                                  p_on=p_on, scale_mul=scale_mul, scale_add=scale_add, out=out)
+                    b["d_state64"][:n].copy_(b["d_state"][:n])  # the API's float64, converted before the PCIe copy
+                    if want_power:
+                        b["d_power64"][:n].copy_(b["d_power"][:n])
+                    b["comp"].record(s_comp)
+                with torch.cuda.stream(s_d2h):
+                    s_d2h.wait_event(b["comp"])
+                    b["state64"][:n].copy_(b["d_state64"][:n], non_blocking=True)
+                    b["prob"][:n].copy_(b["d_prob"][:n], non_blocking=True)
+                    if want_power:
+                        b["power64"][:n].copy_(b["d_power64"][:n], non_blocking=True)
+                    b["d2h"].record(s_d2h)
+                b["n"], b["s"] = n, s
+            nchunks = (N + chunk - 1) // chunk
+            for k in range(2):  # drain, oldest first
+                collect(sets[(nchunks + k) % 2])
+            cur.wait_stream(s_comp)
+        return states, prob, power
+
     # --- profiling ---------------------------------------------------------------------------
     def set_profiling(self, enabled=True):
         _lib.check(self.lib.camal_set_profiling(self._h, int(bool(enabled))))

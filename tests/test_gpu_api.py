@@ -154,3 +154,35 @@ def test_attention_module_and_subsequence_class():
     y = camal._predict_subsequence_class(camal.list_resnet_predictors[0], c["data"])
     firm = np.abs(c["probs"][0][:, 1] - 0.5) > 1e-3
     assert y.dtype == np.int8 and (y[firm] == c["labels"][0][firm]).all()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_streaming_predict_equals_one_shot(dtype):
+    """CamAL.predict's host pipeline (chunks through pinned buffers, copies on their own streams under the kernels):
+    N = 3 x chunk + 7 windows give bit for bit what one resident call gives, states, probabilities and power, with
+    a per-window gate, for float32 and float64 callers; a second call reuses the buffers."""
+    import torch
+    from camal_amd import synth, weights
+    from camal_amd.engine import Ensemble
+    chunk, L = 40, 200
+    N = 3 * chunk + 7
+    x = synth.ukdale_windows(N, L, seed=31).astype(dtype)
+    if dtype == np.float64:
+        x = x - 0.7  # signed input: -1 / -0 states on the float64 path
+    sds = [weights.make_state_dict(k, seed=12, head_gain=3.0) for k in (5, 9, 25)]
+    y = (np.arange(N) % 3 != 0).astype(np.int8)
+    ens = Ensemble(sds, device="cuda:0", precision="fp32")
+    is64 = dtype == np.float64
+    ref = ens.localize(x.astype(np.float32), x64=x if is64 else None, y=y, pred_f64=is64, p_on=2000.0, scale_mul=1000.0)
+    torch.cuda.synchronize()
+    for _ in range(2):
+        states, prob, power = ens.localize_host(x, y=y, p_on=2000.0, scale_mul=1000.0, chunk_windows=chunk)
+        assert states.dtype == np.float64 and states.shape == (N, L)
+        assert np.array_equal(prob, ref["prob"].cpu().numpy())
+        rs = ref["state"].cpu().numpy()
+        assert np.array_equal(states, rs.astype(np.float64)) and np.array_equal(np.signbit(states), np.signbit(rs))
+        assert np.array_equal(power, ref["power"].cpu().numpy().astype(np.float64))
+    s1, _p, _ = ens.localize_host(x[:5], chunk_windows=chunk)  # fewer windows than a chunk, no power, no gate
+    r1 = ens.localize(x[:5].astype(np.float32), x64=x[:5] if is64 else None, pred_f64=is64)
+    assert np.array_equal(s1, r1["state"].cpu().numpy().astype(np.float64))
+    ens.close()
