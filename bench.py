@@ -263,14 +263,11 @@ def run_train(name, wl, steps, warmup, R, args, min_seconds=0.0):
         torch.manual_seed(k)  # same initial weights on every rank (and TrainEngine broadcasts rank 0's anyway)
         engines.append(TrainEngine(CamALResNet(kernel_size=k), dev, B, L))
 
+    from camal_amd.trainer import MemberStreams
+    members = MemberStreams(engines)  # one HIP stream per member: independent members overlap on the device
+
     def step():
-        # a member's gradient all-reduce (N > 1) runs under the next member's forward and backward
-        pending = []
-        for e in engines:
-            e.forward_backward(x, y)
-            pending.append(e.start_grad_allreduce())
-        for e, p in zip(engines, pending):
-            e.optimizer_step(1e-3, 1e-2, pending=p)
+        members.step(x, y, 1e-3, 1e-2)
 
     steps, _ = warm_up(step, steps, warmup, R, min_seconds)
     R.sync()

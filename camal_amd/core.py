@@ -99,6 +99,10 @@ class CamAL(object):
         # ranks (they are independent, core.py:104-158), each trained whole on one GPU with no gradient exchange;
         # the logs are gathered once at the end.  False: every rank trains every candidate data-parallel.
         self.member_parallel = False
+        # > 1: this rank's candidates train side by side on one GPU, that many at a time, each in its own host thread
+        # and HIP stream with its own shuffle generator (one member's short kernels fill the gaps of another's).
+        # Not with data-parallel training over several ranks (their collectives must be issued in one order).
+        self.member_streams = 1
         self._ensemble = None
 
     # ------------------------------------------------------------------ train (core.py:47-189)
@@ -132,31 +136,60 @@ class CamAL(object):
         spread = bool(self.member_parallel) and world > 1
         local_results = {}
 
-        idx_clf = 0
+        def run_candidate(idx, kernel_size, nth_try, generator=None, resnet_inst=None):
+            if resnet_inst is None:
+                resnet_inst = CamALResNet(kernel_size=kernel_size, **self.resnet_kwargs)
+            train_loader = TSLoader(X_train, y_train, batch_size=training_kwargs["batch_size"], shuffle=True, generator=generator)
+            valid_loader = TSLoader(X_valid, y_valid, batch_size=1, shuffle=False, generator=generator)
+            test_loader = TSLoader(X_test, y_test, batch_size=1, shuffle=False, generator=generator)
+            clf_trainer = BasedClassifTrainer(
+                resnet_inst, train_loader=train_loader, valid_loader=valid_loader,
+                learning_rate=training_kwargs["lr"], weight_decay=training_kwargs["weight_decay"],
+                patience_es=training_kwargs["patience_es"], patience_rlr=training_kwargs["patience_rlr"],
+                n_warmup_epochs=training_kwargs["n_warmup_epochs"], device=self.device,
+                all_gpu=training_kwargs["all_gpu"], data_parallel=not spread)
+            clf_trainer.train(training_kwargs["epochs"])
+            clf_trainer.restore_best_weights()
+            loss_eval, _ = clf_trainer.evaluate(test_loader)
+            print(f"Trained predictor {idx} with kernel size: {kernel_size} (nth_try {nth_try}) - loss: {loss_eval}.")
+            clf_trainer.log["kernel_size"] = kernel_size
+            clf_trainer.log["nth_try"] = nth_try
+            if getattr(clf_trainer, "engine", None) is not None:
+                clf_trainer.engine.close()  # the candidate's training workspace goes back before the next one starts
+            return loss_eval, clf_trainer.log
+
+        jobs, idx_clf = [], 0
         for kernel_size in list_kernel_sizes:
             for nth_try in range(n_try_by_kernel):
-                if spread and parallel.member_owner(idx_clf, world) != rank:
-                    idx_clf += 1
-                    continue
-                resnet_inst = CamALResNet(kernel_size=kernel_size, **self.resnet_kwargs)
-                train_loader = TSLoader(X_train, y_train, batch_size=training_kwargs["batch_size"], shuffle=True)
-                valid_loader = TSLoader(X_valid, y_valid, batch_size=1, shuffle=False)
-                test_loader = TSLoader(X_test, y_test, batch_size=1, shuffle=False)
-                clf_trainer = BasedClassifTrainer(
-                    resnet_inst, train_loader=train_loader, valid_loader=valid_loader,
-                    learning_rate=training_kwargs["lr"], weight_decay=training_kwargs["weight_decay"],
-                    patience_es=training_kwargs["patience_es"], patience_rlr=training_kwargs["patience_rlr"],
-                    n_warmup_epochs=training_kwargs["n_warmup_epochs"], device=self.device,
-                    all_gpu=training_kwargs["all_gpu"], data_parallel=not spread)
-                clf_trainer.train(training_kwargs["epochs"])
-                clf_trainer.restore_best_weights()
-                loss_eval, _ = clf_trainer.evaluate(test_loader)
-                print(f"Trained predictor {idx_clf} with kernel size: {kernel_size} (nth_try {nth_try}) - loss: {loss_eval}.")
-
-                clf_trainer.log["kernel_size"] = kernel_size
-                clf_trainer.log["nth_try"] = nth_try
-                local_results[f"Predictor_{idx_clf}"] = (loss_eval, clf_trainer.log)
+                if not (spread and parallel.member_owner(idx_clf, world) != rank):
+                    jobs.append((idx_clf, kernel_size, nth_try))
                 idx_clf += 1
+
+        n_side = int(self.member_streams or 1)
+        if n_side > 1 and (world == 1 or spread) and len(jobs) > 1:
+            import torch
+            from concurrent.futures import ThreadPoolExecutor
+            dev = torch.device(self.device)
+            base = int(torch.empty((), dtype=torch.int64).random_().item())  # one draw: reproducible under manual_seed
+            # initial weights come from the global RNG: drawn here, in candidate order, before the threads start
+            models = {job[0]: CamALResNet(kernel_size=job[1], **self.resnet_kwargs) for job in jobs}
+
+            def threaded(job):
+                idx = job[0]
+                gen = torch.Generator().manual_seed((base + 7919 * idx) % (1 << 62))
+                with torch.cuda.device(dev):
+                    stream = torch.cuda.Stream(dev)
+                    with torch.cuda.stream(stream):
+                        out = run_candidate(*job, generator=gen, resnet_inst=models[idx])
+                    stream.synchronize()
+                return idx, out
+
+            with ThreadPoolExecutor(max_workers=n_side) as pool:
+                for idx, out in pool.map(threaded, jobs):
+                    local_results[f"Predictor_{idx}"] = out
+        else:
+            for job in jobs:
+                local_results[f"Predictor_{job[0]}"] = run_candidate(*job)
 
         if spread:
             local_results = parallel.merge_member_logs(local_results)

@@ -203,3 +203,43 @@ def test_trainer_with_validation_vs_reference():
     assert abs(tr.log["value_best_loss"] - float(c["value_best_loss"])) < 2e-2 * float(c["value_best_loss"])
     loss, _ = tr.evaluate(TSLoader(xv, yv, batch_size=1))
     assert abs(loss - float(c["eval_loss"])) < 2e-2 * float(c["eval_loss"])
+
+
+def test_camal_train_members_side_by_side():
+    """CamAL.member_streams: the candidates train concurrently on one GPU (a host thread + HIP stream + shuffle
+    generator each).  Reproducible under torch.manual_seed, same selection logic and log schema as the sequential
+    loop, and each member's result equals training that member ALONE with the same generator."""
+    import torch
+    from camal_amd import CamAL, synth
+    from camal_amd.resnet import CamALResNet
+    from camal_amd.trainer import BasedClassifTrainer, TSLoader
+    x, y = synth.ideal_windows(96, 64, seed=3)
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(11)
+        camal = CamAL(n_predictors=2, device="cuda:0")
+        camal.member_streams = 3
+        camal.train((x[:64], y[:64]), (x[64:80], y[64:80]), (x[80:], y[80:]), list_kernel_sizes=[5, 7, 9], epochs=3, batch_size=16)
+        runs.append(camal.camal_logs)
+    a, b = runs
+    assert a["camal_predictors_id"] == b["camal_predictors_id"] and len(a["camal_predictors_id"]) == 2
+    assert set(a["ensemble_training_logs"]) == {"Predictor_0", "Predictor_1", "Predictor_2"}
+    for n in a["ensemble_training_logs"]:
+        la, lb = a["ensemble_training_logs"][n], b["ensemble_training_logs"][n]
+        assert la["loss_train_history"] == lb["loss_train_history"] and la["loss_valid_history"] == lb["loss_valid_history"]
+        assert ("best_model_state_dict" in la) == (n in a["camal_predictors_id"])
+    # member 1 (k = 7) trained ALONE from the same initial weights with the same generator: same histories
+    torch.manual_seed(11)
+    base = int(torch.empty((), dtype=torch.int64).random_().item())
+    models = [CamALResNet(kernel_size=k) for k in (5, 7, 9)]
+    gen = torch.Generator().manual_seed((base + 7919 * 1) % (1 << 62))
+    from camal_amd.core import undersampler
+    xu, yu = undersampler(x[:64], y[:64], sampling_strategy="auto", seed=0)  # what CamAL.train feeds its trainers
+    tr = BasedClassifTrainer(models[1], train_loader=TSLoader(xu, yu, batch_size=16, shuffle=True, generator=gen),
+                             valid_loader=TSLoader(x[64:80], y[64:80], batch_size=1, generator=gen), learning_rate=1e-3,
+                             weight_decay=0, patience_es=5, patience_rlr=3, n_warmup_epochs=1, device="cuda:0")
+    tr.train(3)
+    l1 = a["ensemble_training_logs"]["Predictor_1"]
+    assert tr.loss_train_history == l1["loss_train_history"] and tr.loss_valid_history == l1["loss_valid_history"]
+    states = camal.predict(x[80:])
+    assert states.shape == (16, 64)
