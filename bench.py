@@ -182,13 +182,15 @@ def run_inference(name, wl, steps, warmup, R, args, min_seconds=0.0, with_cpu_in
             "kernel_ms_per_step": {k: v[1] / steps for k, v in prof.items()},
             "sanity": {"state_on_fraction": on_frac, "windows_voted_on": vote_frac},
         }
-        if wl["precision"] == "bf16":
+        if wl["precision"] == "bf16" and not args.no_extras:
             res["sanity"]["bf16_vs_fp32"] = bf16_agreement(sds, x, out, dev)
         # the same box's plain streaming kernels (tools/hbm_probe.hip) as denominators beside the 8 TB/s spec:
         # a 1 GiB float4 copy (nothing cached), and the post kernel's own read/write mix at its own size in
         # back-to-back launches (the Infinity Cache holds those buffers: an upper bound the pipeline cannot see,
         # its CAM rows were written tens of milliseconds of HBM traffic earlier)
         try:
+            if args.no_extras:
+                raise RuntimeError("skipped (--no-extras)")
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import hbm_probe
             nr = max(1, int(round(len(ks) * vote_frac)) + 1)
@@ -199,7 +201,7 @@ def run_inference(name, wl, steps, warmup, R, args, min_seconds=0.0, with_cpu_in
             rp["frac_of_copy"] = post_gbs / copy if copy else None
         except Exception as e:  # noqa: BLE001 — a measurement extra, never fatal
             res["roofline_post"]["copy_gbs"] = f"probe failed: {e}"
-    if R.rank == 0 and name == "ensemble_bf16" and R.world == 1:
+    if R.rank == 0 and name == "ensemble_bf16" and R.world == 1 and not args.no_extras:
         res["host_to_host"] = host_to_host(ens, wl)
     ens.close()
     del ens, out, x
@@ -383,13 +385,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="resnet_fp32", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="headline workload (default resnet_fp32 = configs[1]); naming one turns `--also auto` off")
     ap.add_argument("--also", default="auto", choices=["auto", "all", "none"],
                     help="time the other workloads too (auto: only when --workload is the default headline)")
     ap.add_argument("--also-seconds", type=float, default=2.0, help="minimum timed region of each `also` workload")
     ap.add_argument("--batch", type=int, default=0, help="windows per GPU per step (default: workload's)")
     ap.add_argument("--chunk", type=int, default=0, help="windows per internal pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the timed steps (profiling runs): no bf16-vs-fp32 check, host-to-host pass or HBM probe")
     ap.add_argument("--deadline", type=float, default=900.0, help="seconds after which rank 0 prints what it has")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU rehearsal of the launch path: ranks, gloo process group, barrier, MAX; no GPU work")
@@ -427,10 +432,12 @@ def main():
         return
 
     R = Ranks(rank, world, dev, dist)
+    explicit = args.workload is not None
+    args.workload = args.workload or "resnet_fp32"
     wl = dict(WORKLOADS[args.workload])
     if args.batch:
         wl["B"] = args.batch
-    also = [] if args.also == "none" or (args.also == "auto" and args.workload != "resnet_fp32") else \
+    also = [] if args.also == "none" or (args.also == "auto" and explicit) else \
         [n for n in ORDER if n != args.workload]
 
     line = {}

@@ -7,4 +7,4 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 WL=$1; TAG=$2; CTR=$3; RE=${4:-.}
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 300 rocprofv3 --pmc $CTR --kernel-include-regex "$RE" --output-format csv -d "$R/gpurun_out/pmc_$TAG" -o "$TAG" -- \
-    python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --workload "$WL" > "$R/gpurun_out/pmc_$TAG.log" 2>&1
+    python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-extras --workload "$WL" > "$R/gpurun_out/pmc_$TAG.log" 2>&1

@@ -9,11 +9,8 @@ for wl in resnet_fp32 ensemble_bf16 long_bf16 train_fp32; do
   bash tools/profile.sh $wl ${TAG}_$wl > /dev/null
 done
 for wl in resnet_fp32 ensemble_bf16; do
-  bash tools/pmc.sh $wl ${TAG}_${wl}_fetch "FETCH_SIZE" "conv_kernel|block|post_kernel"
-  bash tools/pmc.sh $wl ${TAG}_${wl}_write "WRITE_SIZE" "conv_kernel|block|post_kernel"
+  bash tools/pmc.sh $wl ${TAG}_${wl}_fetch "FETCH_SIZE" "conv_kernel|block|post_"
+  bash tools/pmc.sh $wl ${TAG}_${wl}_write "WRITE_SIZE" "conv_kernel|block|post_"
 done
-timeout -k 10 300 python bench.py > gpurun_out/${TAG}_bench_resnet_fp32.json
-for wl in ensemble_bf16 ensemble_fp32 long_bf16 train_fp32; do
-  timeout -k 10 300 python bench.py --workload $wl --no-cpu-baseline > gpurun_out/${TAG}_bench_$wl.json
-done
+timeout -k 10 600 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_all.json
 echo profiles done

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def kernel_class(name):
-    if "post_kernel" in name:
+    if "post_kernel" in name or "post_stream_kernel" in name:
         return "post"
     if "conv_kernel" in name or "block_kernel" in name or "block1_kernel" in name:
         return "conv"
