@@ -36,6 +36,7 @@ SIGNATURES = {
     "camal_set_member_weights": (_i, [_vp, _i, C.POINTER(C.c_float), _sz]),
     "camal_set_chunk_windows": (_i, [_vp, _i]),
     "camal_set_fused": (_i, [_vp, _i]),
+    "camal_reserve": (_i, [_vp, _i, _i]),
     "camal_forward_cam": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "camal_localize": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "camal_postprocess": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _vp, _vp, _vp, _vp, _vp]),
@@ -55,6 +56,7 @@ SIGNATURES = {
     "camal_trainer_destroy": (_i, [_vp]),
     "camal_trainer_set_grad_scale": (_i, [_vp, C.c_float]),
     "camal_train_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, C.c_float, _vp, _vp, _vp, _vp, _vp]),
+    "camal_ce_eval": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "camal_adamw_step": (_i, [_vp, _vp, _vp, _vp, _sz, _i, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
     "camal_set_profiling": (_i, [_vp, _i]),
     "camal_get_profile": (_i, [_vp, C.POINTER(_i), C.POINTER(_d)]),

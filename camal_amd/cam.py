@@ -9,7 +9,6 @@ never even written to HBM).  ``run_batch`` is the batched form ``CamAL.predict``
 from __future__ import annotations
 
 import numpy as np
-import torch
 
 
 class CAM:
@@ -36,12 +35,16 @@ class CAM:
         x = np.asarray(data)
         want = 1 if returned_cam_for_label is None else int(returned_cam_for_label)
         logits, cam = eng.forward_cam(x, cam_label=want)
-        probs = torch.softmax(logits[0], dim=1)
-        labels = torch.topk(probs, 1)[1][:, 0].int()
+        lg = logits[0].cpu().numpy()
+        cams = cam[0].cpu().numpy()
+        # F.softmax(logits, dim=1) and topk(1) (class_activation_map.py:59,64) on two float32 logits per window: host
+        e = np.exp(lg - lg.max(axis=1, keepdims=True))
+        probs = (e / e.sum(axis=1, keepdims=True)).astype(np.float32)
+        labels = (probs[:, 1] > probs[:, 0]).astype(np.int32)  # a tie goes to class 0
         if returned_cam_for_label is None:
             # class_activation_map.py:69-70: CAM of the predicted class; redo the rows that predicted 0
-            zero = (labels == 0).nonzero()[:, 0]
+            zero = np.flatnonzero(labels == 0)
             if len(zero):
-                _, cam0 = eng.forward_cam(torch.as_tensor(x)[zero.cpu()], cam_label=0)
-                cam[0][zero] = cam0[0]
-        return cam[0].cpu().numpy(), labels.cpu().numpy(), probs.cpu().numpy()
+                _, cam0 = eng.forward_cam(x[zero], cam_label=0)
+                cams[zero] = cam0[0].cpu().numpy()
+        return cams, labels, probs

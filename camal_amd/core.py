@@ -36,23 +36,70 @@ def nilmdataset_to_clfdataset(data):
     return data[:, 0, 0, :], np.array(labels)
 
 
+def _undersampling_targets(y, sampling_strategy):
+    """{class: number of samples to keep} of the classes that get under-sampled, as imbalanced-learn resolves
+    ``sampling_strategy`` for an under-sampler (imblearn/utils/_validation.py, declared ``imbalanced-learn>=0.13.0``
+    in the reference's pyproject.toml; the package is not installed here, so this restates its documented rules):
+    'majority', 'not minority' (= 'auto'), 'not majority', 'all' -> the minority class's count for the classes
+    named; a float r (binary only) -> the majority keeps int(n_minority / r); a dict -> its own counts; a callable ->
+    its dict."""
+    classes, counts = np.unique(y, return_counts=True)
+    stats = {int(c): int(n) for c, n in zip(classes, counts)}
+    first_seen = list(dict.fromkeys(int(v) for v in y))  # Counter(y)'s key order: ties go to the first class seen
+    n_min = min(stats.values())
+    n_max = max(stats.values())
+    c_min = min(first_seen, key=lambda c: stats[c])
+    c_maj = max(first_seen, key=lambda c: stats[c])
+    if callable(sampling_strategy):
+        sampling_strategy = sampling_strategy(y)
+    if isinstance(sampling_strategy, dict):
+        for c, n in sampling_strategy.items():
+            if c not in stats:
+                raise ValueError(f"The {c} target class is not present in the data.")
+            if n > stats[c]:
+                raise ValueError("With under-sampling methods, the number of samples in a class should be less or equal "
+                                 f"to the original number of samples. Originally, there is {stats[c]} samples and {n} samples are asked.")
+        return {int(c): int(n) for c, n in sampling_strategy.items()}
+    if isinstance(sampling_strategy, (int, float)) and not isinstance(sampling_strategy, bool):
+        if len(stats) != 2:
+            raise ValueError('"sampling_strategy" can be a float only when the type of target is binary.')
+        r = float(sampling_strategy)
+        if not 0 < r <= 1:
+            raise ValueError(f"When 'sampling_strategy' is a float, it should be in the range (0, 1]. Got {r} instead.")
+        out = {c: int(n_min / r) for c in stats if c != c_min}
+        if any(n > stats[c] for c, n in out.items()):
+            raise ValueError("The specified ratio required to generate new sample in the majority class while trying to "
+                             "remove samples. Please increase the ratio.")
+        return out
+    if sampling_strategy in ("auto", "not minority"):
+        return {c: n_min for c in stats if c != c_min}
+    if sampling_strategy == "majority":
+        return {c_maj: n_min}
+    if sampling_strategy == "not majority":
+        return {c: n_min for c in stats if c != c_maj}
+    if sampling_strategy == "all":
+        return {c: n_min for c in stats}
+    raise ValueError(f"When 'sampling_strategy' is a string, it needs to be one of 'majority', 'not minority', "
+                     f"'not majority', 'all', 'auto'. Got '{sampling_strategy}' instead.")
+
+
 def undersampler(X, y, sampling_strategy="auto", seed=0):
-    """Random under-sampling to the minority-class count, then a seeded shuffle
-    (reference data_processing.py:37-57).  imblearn is not available here: this restates
-    ``RandomUnderSampler(sampling_strategy='auto', random_state=seed)`` (per class, in sorted
-    class order, ``RandomState(seed).choice(n_class, n_min, replace=False)``); exact index
-    parity with imblearn is unpinned."""
-    if sampling_strategy != "auto":
-        raise NotImplementedError("only sampling_strategy='auto'")
+    """Random under-sampling, then a seeded shuffle (reference data_processing.py:37-57: imblearn's
+    ``RandomUnderSampler(sampling_strategy, random_state=seed).fit_resample`` + ``np.random.shuffle``).  imblearn is
+    not available here: this restates RandomUnderSampler (one ``RandomState(seed)``; classes in sorted order; a class
+    that is under-sampled keeps ``choice(range(n), size=target, replace=False)`` of its samples in that order, the
+    others keep all of theirs) and every ``sampling_strategy`` form it documents.  Index-for-index parity with the
+    installed package is unpinned (no copy of it to compare with)."""
     X = np.asarray(X)
     y = np.asarray(y).astype(int).ravel()
-    classes, counts = np.unique(y, return_counts=True)
-    n_min = counts.min()
+    targets = _undersampling_targets(y, sampling_strategy)
     rs = np.random.RandomState(seed)
     idx = []
-    for c, n in zip(classes, counts):
+    for c in np.unique(y):
         members = np.flatnonzero(y == c)
-        idx.append(members if n == n_min else members[rs.choice(range(n), size=n_min, replace=False)])
+        if int(c) in targets:
+            members = members[rs.choice(range(len(members)), size=targets[int(c)], replace=False)]
+        idx.append(members)
     idx = np.concatenate(idx)
     mat = np.concatenate((X[idx], y[idx].reshape(-1, 1)), axis=1)
     np.random.seed(seed)

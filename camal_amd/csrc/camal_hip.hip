@@ -647,6 +647,17 @@ int camal_set_chunk_windows(camal_ctx* c, int windows) {
     return 0;
 }
 
+int camal_reserve(camal_ctx* c, int B, int L) {
+    if (!c) return fail(CAMAL_ERR_ARG, "null context");
+    if (B < 1 || L < 1) return fail(CAMAL_ERR_ARG, "B and L must be >= 1");
+    HIP_TRY(hipSetDevice(c->device));
+    const int BC = std::min(B, auto_chunk(c, L));
+    const long long fit = (1LL << 30) / ((long long)c->E * L * 4);
+    const int PB = std::min(B, std::max(BC, (int)std::min<long long>(c->post_windows, fit) / BC * BC));  // as camal_localize
+    Workspace w;
+    return ensure_workspace(c, BC, PB, L, &w);
+}
+
 int camal_set_member_weights(camal_ctx* c, int member, const float* f, size_t n_floats) {
     if (!c || !f) return fail(CAMAL_ERR_ARG, "null argument");
     if (member < 0 || member >= c->E) return fail(CAMAL_ERR_ARG, "member index out of range");

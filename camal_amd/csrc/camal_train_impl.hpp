@@ -440,6 +440,14 @@ int camal_train_fwd_bwd(camal_trainer* t, const float* params, float* running, c
     return 0;
 }
 
+int camal_ce_eval(const float* logits, const int* labels, int B, float* loss_out, int* pred_out, void* stream) {
+    if (!logits || !labels || !loss_out || !pred_out) return fail(CAMAL_ERR_ARG, "null argument");
+    if (B < 1) return fail(CAMAL_ERR_ARG, "B must be >= 1");
+    hipLaunchKernelGGL(ce_eval_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, labels, B, loss_out, pred_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int camal_adamw_step(float* params, const float* grads, float* m, float* v, size_t n, int step, float lr, float beta1,
                      float beta2, float eps, float weight_decay, void* stream) {
     if (!params || !grads || !m || !v) return fail(CAMAL_ERR_ARG, "null argument");

@@ -407,6 +407,19 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restric
     }
 }
 
+// ---- evaluation: per-window cross-entropy and predicted label from eval-mode logits (torch_trainer.py:188-193,316-321)
+// loss[b] = -log_softmax(logits[b])[label[b]] in float32, pred[b] = argmax (the first maximum, like torch.max)
+__global__ __launch_bounds__(256) void ce_eval_kernel(const float* __restrict__ logits, const int* __restrict__ labels,
+                                                      int B, float* __restrict__ loss, int* __restrict__ pred) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float l0 = logits[2 * b], l1 = logits[2 * b + 1];
+    const float m = fmaxf(l0, l1);
+    const float den = expf(l0 - m) + expf(l1 - m);
+    loss[b] = -((labels[b] ? l1 : l0) - m - logf(den));
+    pred[b] = l1 > l0 ? 1 : 0;
+}
+
 // ---- adjoint of the replicate padding ------------------------------------------------------------
 // dxp [B][L + 2 pad][C] is the gradient w.r.t. the PADDED input; positions outside [0, L) were copies
 // of the edge samples, so their gradients fold onto t = 0 and t = L - 1.

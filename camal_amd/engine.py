@@ -96,6 +96,10 @@ class Ensemble:
         """True (default): fused-block kernels for blocks 2/3; False: one kernel per ConvBlock."""
         _lib.check(self.lib.camal_set_fused(self._h, int(bool(fused))))
 
+    def reserve(self, B, L):
+        """Allocate the workspace for calls of up to B windows of L steps now (later calls then allocate nothing)."""
+        _lib.check(self.lib.camal_reserve(self._h, int(B), int(L)))
+
     def set_chunk_windows(self, n):
         _lib.check(self.lib.camal_set_chunk_windows(self._h, int(n)))
 

@@ -324,14 +324,24 @@ def forward_train(model, x):
         eng.close()
 
 
+def _is_default_ce(criterion):
+    """nn.CrossEntropyLoss() as the reference constructs it: mean reduction, no class weights, no smoothing."""
+    return (isinstance(criterion, torch.nn.CrossEntropyLoss) and criterion.weight is None and criterion.reduction == "mean"
+            and criterion.label_smoothing == 0.0 and criterion.ignore_index == -100)
+
+
 class BasedClassifTrainer(object):
     def __init__(self, model, train_loader, valid_loader=None, learning_rate=1e-3, weight_decay=1e-2,
                  criterion=None, patience_es=None, patience_rlr=None, device="cuda", all_gpu=False,
                  valid_criterion=None, n_warmup_epochs=0, f_metrics=Classifmetrics(), verbose=False,
                  plotloss=False, save_fig=False, path_fig=None, save_checkpoint=False, path_checkpoint=None,
                  data_parallel=True):
-        if criterion is not None or valid_criterion is not None:
-            raise NotImplementedError("the HIP training step implements nn.CrossEntropyLoss() (the reference default)")
+        if criterion is not None and not _is_default_ce(criterion):
+            raise NotImplementedError("the HIP training step implements nn.CrossEntropyLoss() with default arguments "
+                                      "(the reference's default criterion, torch_trainer.py:20)")
+        # valid_criterion (torch_trainer.py:23,53-56): None or the default cross-entropy -> the HIP evaluation kernel;
+        # anything else is applied to the eval-mode logits batch by batch, in torch
+        self.valid_criterion = None if valid_criterion is None or _is_default_ce(valid_criterion) else valid_criterion
         self._init_host(model, train_loader, valid_loader, learning_rate, weight_decay, patience_es, patience_rlr, device,
                         all_gpu, n_warmup_epochs, f_metrics, verbose, plotloss, save_fig, path_fig, save_checkpoint,
                         path_checkpoint)
@@ -353,6 +363,8 @@ class BasedClassifTrainer(object):
         self.path_checkpoint = path_checkpoint if path_checkpoint is not None else os.getcwd() + os.sep + "model"
         self.patience_rlr, self.patience_es, self.n_warmup_epochs = patience_rlr, patience_es, n_warmup_epochs
         self.lr, self.weight_decay = learning_rate, weight_decay
+        if not hasattr(self, "valid_criterion"):
+            self.valid_criterion = None
         self.scheduler = ReduceLROnPlateau(learning_rate, patience=patience_rlr, eps=1e-7) if patience_rlr is not None else None
 
         self.log = {}
@@ -496,11 +508,24 @@ class BasedClassifTrainer(object):
         if hasattr(loader, "draw_base_seed"):
             loader.draw_base_seed()  # the reference iterates the loader here (torch_trainer.py:182,311)
         X = loader.samples[:, 0, :]
-        logits = self.model(X.astype(np.float32))
-        labels = torch.as_tensor(loader.labels).to(logits.device).float().long()
-        per_sample = torch.nn.functional.cross_entropy(logits.float(), labels, reduction="none")
-        n, bs = len(labels), loader.batch_size
-        losses = [per_sample[s:s + bs].mean().item() for s in range(0, n, bs)] if bs > 1 else per_sample.cpu().numpy().tolist()
-        y_hat = torch.max(logits, 1)[1].cpu().numpy()
+        logits = self.model(X.astype(np.float32)).float().contiguous()
+        n, bs = len(loader.labels), loader.batch_size
+        if self.valid_criterion is None:
+            lib = _lib.load()
+            dev = logits.device
+            with torch.cuda.device(dev):
+                labels = torch.as_tensor(np.asarray(loader.labels, dtype=np.float32).astype(np.int32)).to(dev)
+                loss_d = torch.empty(n, dtype=torch.float32, device=dev)
+                pred_d = torch.empty(n, dtype=torch.int32, device=dev)
+                _lib.check(lib.camal_ce_eval(_lib.ptr(logits), _lib.ptr(labels), n, _lib.ptr(loss_d), _lib.ptr(pred_d),
+                                             C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+            per_sample = loss_d.cpu().numpy()
+            y_hat = pred_d.cpu().numpy().astype(np.int64)
+            # the reference logs loss.item() of every batch (float32 means), batch size 1 in CamAL.train
+            losses = per_sample.tolist() if bs == 1 else [float(per_sample[s:s + bs].mean(dtype=np.float32)) for s in range(0, n, bs)]
+        else:  # a caller-supplied validation criterion: torch, batch by batch like the reference
+            labels = torch.as_tensor(np.asarray(loader.labels)).to(logits.device).float().long()
+            losses = [float(self.valid_criterion(logits[s:s + bs], labels[s:s + bs]).item()) for s in range(0, n, bs)]
+            y_hat = torch.max(logits, 1)[1].cpu().numpy()
         self.model.train()
         return losses, loader.labels.astype(np.float32), y_hat

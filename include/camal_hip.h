@@ -77,6 +77,11 @@ int camal_set_member_weights(camal_ctx* ctx, int member, const float* folded_hos
  * 1024 windows of 1440 steps, 256 of 10080).                                                */
 int camal_set_chunk_windows(camal_ctx* ctx, int windows);
 
+/* Size the context's workspace now for calls of up to B windows of L steps (camal_forward_cam, camal_localize), so
+ * that those calls allocate nothing later: without it the first call of a larger shape frees and re-allocates the
+ * workspace on the call path (not capturable in a HIP graph, and a first-call latency of its own).            */
+int camal_reserve(camal_ctx* ctx, int B, int L);
+
 /* 1 (default for bf16; fp32 defaults to 0; env CAMAL_FUSED overrides): blocks 2 and 3 of every member run as fused-block kernels (three ConvBlocks per
  * launch, intermediates in LDS); 0: one kernel per ConvBlock.  Same arithmetic per element; the
  * pooled sums are taken over different tile sizes, so logits agree to fp32 rounding.          */
@@ -235,6 +240,12 @@ int camal_train_fwd_bwd(camal_trainer* t, const float* params_dev, float* bn_run
                         const float* x_dev, const int* y_dev, int B, int L, float bn_momentum,
                         float* grads_dev, float* logits_dev, float* loss_dev, int* ncorrect_dev,
                         void* stream);
+
+/* Evaluation loss of BasedClassifTrainer.evaluate / __evaluate (torch_trainer.py:188-193,316-321) from eval-mode
+ * logits (camal_forward_cam): per-window cross-entropy (float32, -log_softmax[label]) and predicted label (argmax,
+ * the first maximum like torch.max).  logits_dev [B][2] float32, labels_dev [B] int32, loss_out [B] float32,
+ * pred_out [B] int32; the caller forms the per-batch means the reference logs.                                    */
+int camal_ce_eval(const float* logits_dev, const int* labels_dev, int B, float* loss_out, int* pred_out, void* stream);
 
 /* torch.optim.AdamW update of a flat buffer (torch_trainer.py:35,292): decoupled weight decay,
  * bias-corrected moments; `step` counts from 1.                                                */

@@ -123,6 +123,32 @@ def test_undersampler_balances_and_is_seeded():
     assert (ya == 1).sum() == (ya == 0).sum() == y.sum()
 
 
+def test_undersampler_sampling_strategies():
+    """imblearn's documented sampling_strategy forms (string, float ratio, dict, callable) on three classes / two."""
+    from camal_amd.core import undersampler
+    rng = np.random.default_rng(1)
+    X = rng.normal(size=(300, 4))
+    y3 = np.repeat([0, 1, 2], [150, 100, 50])
+    cnt = lambda yy: [int((yy == c).sum()) for c in (0, 1, 2)]  # noqa: E731
+    assert cnt(undersampler(X, y3, "auto")[1]) == cnt(undersampler(X, y3, "not minority")[1]) == [50, 50, 50]
+    assert cnt(undersampler(X, y3, "majority")[1]) == [50, 100, 50]
+    assert cnt(undersampler(X, y3, "not majority")[1]) == [150, 50, 50]
+    assert cnt(undersampler(X, y3, "all")[1]) == [50, 50, 50]
+    assert cnt(undersampler(X, y3, {0: 70, 1: 60})[1]) == [70, 60, 50]
+    assert cnt(undersampler(X, y3, lambda yy: {0: 10})[1]) == [10, 100, 50]
+    y2 = np.repeat([0, 1], [240, 60])
+    assert cnt(undersampler(X, y2, 0.5)[1]) == [120, 60, 0]
+    for bad in (0.1, 1.5, "minority", {0: 999}, {7: 1}):
+        with pytest.raises(ValueError):
+            undersampler(X, y2, bad)
+    with pytest.raises(ValueError):
+        undersampler(X, y3, 0.5)  # a float only for binary targets
+    # every kept row is a row of X with its own label, no row twice
+    Xs, ys = undersampler(X, y3, "all", seed=3)
+    rows = {tuple(np.float32(r)): int(l) for r, l in zip(X, y3)}
+    assert len({tuple(r) for r in Xs}) == len(Xs) and all(rows[tuple(r)] == int(l) for r, l in zip(Xs, ys))
+
+
 def test_metrics_keys_and_values():
     from camal_amd.metrics import Classifmetrics, NILMmetrics
     y = np.array([0, 0, 1, 1, 1, 0])

@@ -243,3 +243,63 @@ def test_camal_train_members_side_by_side():
     assert tr.loss_train_history == l1["loss_train_history"] and tr.loss_valid_history == l1["loss_valid_history"]
     states = camal.predict(x[80:])
     assert states.shape == (16, 64)
+
+
+def test_criterion_arguments_and_reserved_workspace():
+    """criterion / valid_criterion of the reference's constructor (torch_trainer.py:20,23,52-56): the default
+    cross-entropy object is accepted, another training criterion is refused, a caller's validation criterion is
+    applied to the eval-mode logits; evaluation losses equal torch's cross-entropy on the same logits."""
+    import torch
+    from camal_amd import synth
+    from camal_amd.resnet import CamALResNet
+    from camal_amd.trainer import BasedClassifTrainer, TSLoader
+    x, y = synth.ideal_windows(40, 64, seed=8)
+    torch.manual_seed(3)
+    m = CamALResNet(kernel_size=5)
+    tl, vl = TSLoader(x[:32], y[:32], batch_size=16), TSLoader(x[32:], y[32:], batch_size=1)
+    with pytest.raises(NotImplementedError):
+        BasedClassifTrainer(m, tl, criterion=torch.nn.CrossEntropyLoss(label_smoothing=0.1), device="cuda:0")
+    tr = BasedClassifTrainer(m, tl, valid_loader=vl, criterion=torch.nn.CrossEntropyLoss(), device="cuda:0", weight_decay=0)
+    tr.train(1)
+    loss, metrics = tr.evaluate(vl)
+    m.eval()
+    logits = m(x[32:]).float()
+    labels = torch.as_tensor(y[32:]).to(logits.device).long()
+    ref = torch.nn.functional.cross_entropy(logits, labels, reduction="none").cpu().numpy()
+    assert abs(loss - ref.mean()) < 1e-6 and abs(tr.loss_valid_history[0] - ref.mean()) < 1e-6
+    assert metrics["ACCURACY"] == round(float((logits.argmax(1) == labels).float().mean()), 5)
+    # a validation criterion of the caller's: summed instead of averaged, batches of 4
+    m.train()
+    tr2 = BasedClassifTrainer(m, tl, valid_loader=TSLoader(x[32:], y[32:], batch_size=4), device="cuda:0",
+                              valid_criterion=torch.nn.CrossEntropyLoss(reduction="sum"))
+    l2, _ = tr2.evaluate(TSLoader(x[32:], y[32:], batch_size=4))
+    m.eval()
+    ref2 = torch.nn.functional.cross_entropy(m(x[32:]).float(), labels, reduction="none").cpu().numpy()
+    assert abs(l2 - ref2.reshape(2, 4).sum(axis=1).mean()) < 1e-4
+
+
+def test_reserve_keeps_the_call_path_free_of_allocations():
+    """camal_reserve: the workspace is sized once; smaller and equal shapes afterwards give the same numbers as a
+    fresh context (and the library's workspace pointer does not move: observed through HIP's free-memory counter)."""
+    import torch
+    from camal_amd import synth, weights
+    from camal_amd.engine import Ensemble
+    sds = [weights.make_state_dict(k, seed=4, head_gain=3.0) for k in (5, 9)]
+    x = synth.ukdale_windows(24, 300, seed=6)
+    a = Ensemble(sds, device="cuda:0", precision="fp32")
+    a.reserve(24, 300)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    ra = a.localize(x, p_on=2000.0, scale_mul=1000.0)
+    rb = a.localize(x[:7, :128].copy(), p_on=2000.0, scale_mul=1000.0)
+    torch.cuda.synchronize()
+    outputs = sum(t.numel() * t.element_size() for r in (ra, rb) for t in r.values()) + x.nbytes + x[:7, :128].nbytes
+    assert free0 - torch.cuda.mem_get_info()[0] <= outputs + (8 << 20)  # only the callers' tensors (torch's pool granularity)
+    b = Ensemble(sds, device="cuda:0", precision="fp32")
+    rc = b.localize(x, p_on=2000.0, scale_mul=1000.0)
+    for k in ("prob", "state", "power"):
+        assert torch.equal(ra[k], rc[k])
+    with pytest.raises(Exception):
+        a.reserve(0, 10)
+    a.close()
+    b.close()
