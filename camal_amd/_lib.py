@@ -32,6 +32,8 @@ SIGNATURES = {
     "camal_create": (_i, [_i, _i, C.POINTER(_i), _i, C.POINTER(_vp)]),
     "camal_create_arch": (_i, [_i, _i, C.POINTER(_i), _i, _i, C.POINTER(_vp)]),
     "camal_member_blob_floats_arch": (_sz, [_i, _i]),
+    "camal_create_widths": (_i, [_i, _i, C.POINTER(_i), _i, _i, _i, C.POINTER(_vp)]),
+    "camal_member_blob_floats_widths": (_sz, [_i, _i, _i]),
     "camal_destroy": (_i, [_vp]),
     "camal_set_member_weights": (_i, [_vp, _i, C.POINTER(C.c_float), _sz]),
     "camal_set_chunk_windows": (_i, [_vp, _i]),
@@ -53,6 +55,9 @@ SIGNATURES = {
     "camal_trainer_create": (_i, [_i, _i, _i, _i, C.POINTER(_vp)]),
     "camal_trainer_create_arch": (_i, [_i, _i, _i, _i, _i, C.POINTER(_vp)]),
     "camal_trainer_param_count_arch": (_sz, [_i, _i]),
+    "camal_trainer_create_widths": (_i, [_i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "camal_trainer_param_count_widths": (_sz, [_i, _i, _i]),
+    "camal_trainer_running_count_widths": (_sz, [_i]),
     "camal_trainer_destroy": (_i, [_vp]),
     "camal_trainer_set_grad_scale": (_i, [_vp, C.c_float]),
     "camal_train_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, C.c_float, _vp, _vp, _vp, _vp, _vp]),

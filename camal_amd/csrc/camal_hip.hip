@@ -31,28 +31,37 @@ int fail(int code, const std::string& msg) {
 
 constexpr int C1 = 64, C2 = 128;  // core.py:37 mid_channels default; CamAL.eval ignores kwargs (:386-390)
 
+// mid_channels the library has kernels for (camal_resnet.py:8,14-16: widths 1 -> mid -> 2 mid -> 2 mid); 64 is what
+// CamAL.eval always builds, 32 and 128 serve CamALResNet(mid_channels=...) on its own and CamAL.train's resnet_kwargs
+bool mid_supported(int mid) { return mid == 32 || mid == 64 || mid == 128; }
+
 // The 9 ConvBlocks of one member: (Cin, Cout, k) with k<0 meaning "the member's kernel size".
 struct ConvShape { int cin, cout, k; };
-const ConvShape kConvs[9] = {{1, C1, -1},  {C1, C1, 7},  {C1, C1, 3},  {C1, C2, -1}, {C2, C2, 7},
-                             {C2, C2, 3},  {C2, C2, -1}, {C2, C2, 7},  {C2, C2, 3}};
+ConvShape conv_shape(int i, int mid = C1) {
+    const int c1 = mid, c2 = 2 * mid;
+    const ConvShape t[9] = {{1, c1, -1},  {c1, c1, 7},  {c1, c1, 3},  {c1, c2, -1}, {c2, c2, 7},
+                            {c2, c2, 3},  {c2, c2, -1}, {c2, c2, 7},  {c2, c2, 3}};
+    return t[i];
+}
 
 // Kernel size of ConvBlock i.  CAMAL_ARCH_CAMAL: (k, 7, 3) per block, replicate padding (camal_resnet.py:31,83);
 // CAMAL_ARCH_RESNET: (7, 5, 3) per block, zero "same" padding (classifiers/resnet.py:31,62).
 int conv_ks(int arch, int i, int k) {
     if (arch == CAMAL_ARCH_RESNET) return i % 3 == 0 ? 7 : (i % 3 == 1 ? 5 : 3);
-    return kConvs[i].k < 0 ? k : kConvs[i].k;
+    return conv_shape(i).k < 0 ? k : conv_shape(i).k;
 }
 
-size_t blob_floats(int k, int arch = CAMAL_ARCH_CAMAL) {
+size_t blob_floats(int k, int arch = CAMAL_ARCH_CAMAL, int mid = C1) {
+    const int c1 = mid, c2 = 2 * mid;
     size_t n = 0;
     for (int i = 0; i < 9; ++i) {
-        const auto& c = kConvs[i];
+        const ConvShape c = conv_shape(i, mid);
         int kk = conv_ks(arch, i, k);
         n += (size_t)c.cout * c.cin * kk + c.cout;
     }
-    n += C1 * 1 + C1;      // residual 1
-    n += C2 * C1 + C2;     // residual 2
-    n += 2 * C2 + 2;       // head
+    n += c1 * 1 + c1;      // residual 1
+    n += (size_t)c2 * c1 + c2;  // residual 2
+    n += 2 * c2 + 2;       // head
     return n;
 }
 
@@ -63,6 +72,7 @@ size_t blob_floats(int k, int arch = CAMAL_ARCH_CAMAL) {
 // fp32 128 -> 64 (only the dgrad of block 2's first conv): one column tile per wave.
 template <typename DT, int CIN, int COUT> struct TileNT { static constexpr int NT = sizeof(DT) == 4 ? 2 : 4; };
 template <> struct TileNT<float, 128, 64> { static constexpr int NT = 1; };
+template <> struct TileNT<float, 256, 128> { static constexpr int NT = 1; };  // dgrad of mid_channels = 128's block 2
 template <typename DT, int CIN, int COUT, int NWC>
 using GeomW = ConvGeom<DT, CIN, COUT, TileNT<DT, CIN, COUT>::NT, NWC>;
 
@@ -70,7 +80,8 @@ using GeomW = ConvGeom<DT, CIN, COUT, TileNT<DT, CIN, COUT>::NT, NWC>;
 template <typename DT, int CIN, int COUT, bool HEAD>
 bool use_small_wg(size_t lds_per_cu, int ks) {
     if (sizeof(DT) != 4) return true;
-    using G = GeomW<DT, CIN, COUT, 4>;
+    if (COUT / 32 > 4) return false;  // 256 out-channels: eight channel tiles need the eight compute waves
+    using G = GeomW<DT, CIN, COUT, (COUT / 32 > 4 ? 8 : 4)>;
     return 2 * (2 * (size_t)G::buf_bytes(ks) + (HEAD ? G::HEAD_BYTES : 0)) <= lds_per_cu;
 }
 
@@ -100,7 +111,8 @@ struct camal_ctx {
     int num_cu = 256;
     size_t lds_per_cu = 160 * 1024;
     int arch = CAMAL_ARCH_CAMAL;
-    float* zero_row = nullptr;  // 512 B of zeros: what a zero-padded layer reads outside the window
+    int mid = C1;  // mid_channels (camal_resnet.py:8): 64, or 32 / 128 through camal_create_widths (fp32, one kernel per ConvBlock)
+    float* zero_row = nullptr;  // 1 KiB of zeros: what a zero-padded layer reads outside the window
     int fused = 1;  // blocks 2 and 3 as fused-block kernels (block_kernel); 0: one conv_kernel per layer
     int fused_block1 = 1;  // with fused: block 1 as block1_kernel (env CAMAL_FUSED_BLOCK1=0: stem + two conv_kernels)
     std::vector<Member> m;
@@ -216,6 +228,7 @@ int block_nwc(size_t lds_per_cu, int k) {
 
 // can this member's blocks 2/3 run fused (LDS budget depends on the first kernel size)?
 bool fused_fits(const camal_ctx* c, int k) {
+    if (c->mid != C1) return false;  // the fused-block kernels exist for the default widths
     if (c->precision == CAMAL_FP32)
         return block_nwc<float, C2, false, true>(c->lds_per_cu, k) && block_nwc<float, C1, true, false>(c->lds_per_cu, k);
     return block_nwc<__bf16, C2, false, true>(c->lds_per_cu, k) && block_nwc<__bf16, C1, true, false>(c->lds_per_cu, k);
@@ -226,12 +239,18 @@ int fused_head_tile(size_t lds_per_cu, int k) {
     return BGeom<DT, C2, 8>::T;
 }
 
+// the per-layer CAM head is the k = 3 ConvBlock on CH = 2 mid channels: its tile configuration follows use_small_wg
+template <int CH>
+int layer_head_tile(size_t lds_per_cu) {
+    return use_small_wg<float, CH, CH, true>(lds_per_cu, 3) ? GeomW<float, CH, CH, 4>::TN : GeomW<float, CH, CH, 8>::TN;
+}
+
 // timesteps per CAM-head tile (decides the layout of the pooled partial sums)
 int head_tile_len(const camal_ctx* c, bool fused, int k) {
-    // the per-layer CAM head is the k = 3 ConvBlock: its tile configuration follows use_small_wg
+    if (c->mid == 32) return layer_head_tile<64>(c->lds_per_cu);
+    if (c->mid == 128) return layer_head_tile<256>(c->lds_per_cu);
     if (c->precision == CAMAL_FP32)
-        return fused ? fused_head_tile<float>(c->lds_per_cu, k)
-                     : (use_small_wg<float, C2, C2, true>(c->lds_per_cu, 3) ? GeomW<float, C2, C2, 4>::TN : GeomW<float, C2, C2, 8>::TN);
+        return fused ? fused_head_tile<float>(c->lds_per_cu, k) : layer_head_tile<C2>(c->lds_per_cu);
     return fused ? fused_head_tile<__bf16>(c->lds_per_cu, k) : GeomW<__bf16, C2, C2, 4>::TN;
 }
 
@@ -241,7 +260,7 @@ int head_tiles(const camal_ctx*, int L) { return (L + 55) / 56; }
 // BC: windows per conv pass (activations); PB >= BC: windows per post-processing launch (CAM rows, logits)
 size_t workspace_layout(const camal_ctx* c, int BC, int PB, int L, Workspace* w, char* base) {
     const size_t es = c->precision == CAMAL_FP32 ? 4 : 2;
-    const size_t n64 = align_up((size_t)BC * L * C1 * es), n128 = align_up((size_t)BC * L * C2 * es);
+    const size_t n64 = align_up((size_t)BC * L * c->mid * es), n128 = align_up((size_t)BC * L * 2 * c->mid * es);
     const int ntiles = head_tiles(c, L);
     size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += bytes; return (void*)p; };
@@ -338,9 +357,11 @@ template <typename DT, int CIN, int COUT, bool RELU, bool HAS_RES, bool HEAD>
 int launch_conv_ex(camal_ctx* c, int num_cu, size_t lds_per_cu, int cam_row, hipStream_t s, const void* wpack,
                    const float* bias, int ks, const void* in, const void* res, void* out, const float* wfc, float* cam,
                    float* part, int BC, int L_out, int L_in, int in_off, const void* zero_row, float* cmax = nullptr) {
-    if (use_small_wg<DT, CIN, COUT, HEAD>(lds_per_cu, ks))
-        return launch_conv_w<DT, CIN, COUT, 4, RELU, HAS_RES, HEAD>(c, num_cu, lds_per_cu, cam_row, s, wpack, bias, ks, in, res,
-                                                                    out, wfc, cam, part, BC, L_out, L_in, in_off, zero_row, cmax);
+    if constexpr (COUT / 32 <= 4) {
+        if (use_small_wg<DT, CIN, COUT, HEAD>(lds_per_cu, ks))
+            return launch_conv_w<DT, CIN, COUT, 4, RELU, HAS_RES, HEAD>(c, num_cu, lds_per_cu, cam_row, s, wpack, bias, ks, in, res,
+                                                                        out, wfc, cam, part, BC, L_out, L_in, in_off, zero_row, cmax);
+    }
     if constexpr (sizeof(DT) == 4) {
         using G8 = GeomW<DT, CIN, COUT, 8>;
         if (2 * (size_t)G8::buf_bytes(ks) + (HEAD ? G8::HEAD_BYTES : 0) <= lds_per_cu || HEAD || TileNT<DT, CIN, COUT>::NT == 1)
@@ -439,42 +460,64 @@ int launch_block1(camal_ctx* c, hipStream_t s, const Member& m, const float* x, 
     return launch_block1_w<DT, 8>(c, s, m, x, out, BC, L);
 }
 
-// One member's conv stack on BC windows: x -> cam row 1 [BC][L] + pooled partials [BC][ntiles][2]
+// One member's conv stack on BC windows, one kernel per ConvBlock, for mid_channels = M (widths 1 -> M -> 2M -> 2M):
+// x -> cam row [BC][L] + pooled partials [BC][ntiles][2].  block1_done: block 1 already ran fused (its output in w.a1)
+template <typename DT, int M>
+int run_member_layers(camal_ctx* c, hipStream_t s, const Member& m, const float* x, int BC, int L, const Workspace& w,
+                      float* cam, float* part, float* cmax, bool block1_done) {
+    constexpr int W1 = M, W2 = 2 * M;
+    int r;
+    if (!block1_done) {
+        {
+            ProfScope ps(c, s, 0);
+            hipLaunchKernelGGL((stem_kernel<DT, W1>), dim3((L + 63) / 64, BC), dim3(256), 0, s, x, m.stem_w, m.stem_b, m.res1_w,
+                               m.res1_b, (DT*)w.a1, (DT*)w.r1, L, m.k, c->arch == CAMAL_ARCH_RESNET);
+            HIP_TRY(hipGetLastError());
+        }
+        // block 1: ConvBlock(7), ConvBlock(3) + residual (camal_resnet.py:35-38,56-58)
+        if ((r = launch_conv<DT, W1, W1, true, false, false>(c, s, m.conv[0], w.a1, nullptr, w.b1, nullptr, nullptr, nullptr, BC, L))) return r;
+        if ((r = launch_conv<DT, W1, W1, true, true, false>(c, s, m.conv[1], w.b1, w.r1, w.a1, nullptr, nullptr, nullptr, BC, L))) return r;
+    }
+    // block 2: residual BN(Conv1x1) first (no ReLU), then ConvBlock(k), (7), (3)+residual
+    if ((r = launch_conv<DT, W1, W2, false, false, false>(c, s, m.res2, w.a1, nullptr, w.r2, nullptr, nullptr, nullptr, BC, L))) return r;
+    if ((r = launch_conv<DT, W1, W2, true, false, false>(c, s, m.conv[2], w.a1, nullptr, w.a2, nullptr, nullptr, nullptr, BC, L))) return r;
+    if ((r = launch_conv<DT, W2, W2, true, false, false>(c, s, m.conv[3], w.a2, nullptr, w.b2, nullptr, nullptr, nullptr, BC, L))) return r;
+    if ((r = launch_conv<DT, W2, W2, true, true, false>(c, s, m.conv[4], w.b2, w.r2, w.a2, nullptr, nullptr, nullptr, BC, L))) return r;
+    // block 3: no skip (camal_resnet.py:40-41,59); last ConvBlock fused with the CAM head
+    if ((r = launch_conv<DT, W2, W2, true, false, false>(c, s, m.conv[5], w.a2, nullptr, w.b2, nullptr, nullptr, nullptr, BC, L))) return r;
+    if ((r = launch_conv<DT, W2, W2, true, false, false>(c, s, m.conv[6], w.b2, nullptr, w.a2, nullptr, nullptr, nullptr, BC, L))) return r;
+    if ((r = launch_conv<DT, W2, W2, true, false, true>(c, s, m.conv[7], w.a2, nullptr, nullptr, m.wfc, cam, part, BC, L, cmax))) return r;
+    return 0;
+}
+
+// One member's conv stack on BC windows at the default widths: fused-block kernels where they apply
 template <typename DT>
 int run_member(camal_ctx* c, hipStream_t s, const Member& m, const float* x, int BC, int L, const Workspace& w,
                float* cam, float* part, float* cmax) {
     int r;
     const bool fused = c->fused && fused_fits(c, m.k);
-    if (fused && c->fused_block1) {
+    const bool b1 = fused && c->fused_block1;
+    if (b1) {
         // block 1 in one launch: x in, 64-channel block output out
         if ((r = launch_block1<DT>(c, s, m, x, w.a1, BC, L))) return r;
-    } else {
-        {
-            ProfScope ps(c, s, 0);
-            hipLaunchKernelGGL(stem_kernel<DT>, dim3((L + 63) / 64, BC), dim3(256), 0, s, x, m.stem_w, m.stem_b, m.res1_w,
-                               m.res1_b, (DT*)w.a1, (DT*)w.r1, L, m.k, c->arch == CAMAL_ARCH_RESNET);
-            HIP_TRY(hipGetLastError());
-        }
-        // block 1: ConvBlock(7), ConvBlock(3) + residual (camal_resnet.py:35-38,56-58)
-        if ((r = launch_conv<DT, C1, C1, true, false, false>(c, s, m.conv[0], w.a1, nullptr, w.b1, nullptr, nullptr, nullptr, BC, L))) return r;
-        if ((r = launch_conv<DT, C1, C1, true, true, false>(c, s, m.conv[1], w.b1, w.r1, w.a1, nullptr, nullptr, nullptr, BC, L))) return r;
     }
     if (fused) {
+        if (!b1) {
+            {
+                ProfScope ps(c, s, 0);
+                hipLaunchKernelGGL((stem_kernel<DT, C1>), dim3((L + 63) / 64, BC), dim3(256), 0, s, x, m.stem_w, m.stem_b, m.res1_w,
+                                   m.res1_b, (DT*)w.a1, (DT*)w.r1, L, m.k, c->arch == CAMAL_ARCH_RESNET);
+                HIP_TRY(hipGetLastError());
+            }
+            if ((r = launch_conv<DT, C1, C1, true, false, false>(c, s, m.conv[0], w.a1, nullptr, w.b1, nullptr, nullptr, nullptr, BC, L))) return r;
+            if ((r = launch_conv<DT, C1, C1, true, true, false>(c, s, m.conv[1], w.b1, w.r1, w.a1, nullptr, nullptr, nullptr, BC, L))) return r;
+        }
         // blocks 2 and 3: one fused kernel each (three ConvBlocks through LDS)
         if ((r = launch_block<DT, C1, true, false>(c, s, m.conv[2], m.conv[3], m.conv[4], &m.res2, w.a1, w.a2, nullptr, nullptr, nullptr, BC, L))) return r;
         if ((r = launch_block<DT, C2, false, true>(c, s, m.conv[5], m.conv[6], m.conv[7], nullptr, w.a2, nullptr, m.wfc, cam, part, BC, L, cmax))) return r;
         return 0;
     }
-    // block 2: residual BN(Conv1x1) first (no ReLU), then ConvBlock(k), (7), (3)+residual
-    if ((r = launch_conv<DT, C1, C2, false, false, false>(c, s, m.res2, w.a1, nullptr, w.r2, nullptr, nullptr, nullptr, BC, L))) return r;
-    if ((r = launch_conv<DT, C1, C2, true, false, false>(c, s, m.conv[2], w.a1, nullptr, w.a2, nullptr, nullptr, nullptr, BC, L))) return r;
-    if ((r = launch_conv<DT, C2, C2, true, false, false>(c, s, m.conv[3], w.a2, nullptr, w.b2, nullptr, nullptr, nullptr, BC, L))) return r;
-    if ((r = launch_conv<DT, C2, C2, true, true, false>(c, s, m.conv[4], w.b2, w.r2, w.a2, nullptr, nullptr, nullptr, BC, L))) return r;
-    // block 3: no skip (camal_resnet.py:40-41,59); last ConvBlock fused with the CAM head
-    if ((r = launch_conv<DT, C2, C2, true, false, false>(c, s, m.conv[5], w.a2, nullptr, w.b2, nullptr, nullptr, nullptr, BC, L))) return r;
-    if ((r = launch_conv<DT, C2, C2, true, false, false>(c, s, m.conv[6], w.b2, nullptr, w.a2, nullptr, nullptr, nullptr, BC, L))) return r;
-    if ((r = launch_conv<DT, C2, C2, true, false, true>(c, s, m.conv[7], w.a2, nullptr, nullptr, m.wfc, cam, part, BC, L, cmax))) return r;
-    return 0;
+    return run_member_layers<DT, C1>(c, s, m, x, BC, L, w, cam, part, cmax, false);
 }
 
 // pooled-sum tiles per window of member m's CAM head
@@ -486,8 +529,11 @@ int member_ntiles(const camal_ctx* c, const Member& m, int L) {
 // logits == nullptr: the caller finalizes the pooled sums itself (camal_localize: header_kernel)
 int run_member_any(camal_ctx* c, hipStream_t s, const Member& m, const float* x, int BC, int L, const Workspace& w,
                    float* cam, float* part, float* logits, float* cmax) {
-    int r = c->precision == CAMAL_FP32 ? run_member<float>(c, s, m, x, BC, L, w, cam, part, cmax)
-                                       : run_member<__bf16>(c, s, m, x, BC, L, w, cam, part, cmax);
+    int r;
+    if (c->mid == 32) r = run_member_layers<float, 32>(c, s, m, x, BC, L, w, cam, part, cmax, false);
+    else if (c->mid == 128) r = run_member_layers<float, 128>(c, s, m, x, BC, L, w, cam, part, cmax, false);
+    else r = c->precision == CAMAL_FP32 ? run_member<float>(c, s, m, x, BC, L, w, cam, part, cmax)
+                                        : run_member<__bf16>(c, s, m, x, BC, L, w, cam, part, cmax);
     if (r || !logits) return r;
     ProfScope ps(c, s, 4);
     const int tl = head_tile_len(c, c->fused && fused_fits(c, m.k), m.k);
@@ -590,7 +636,20 @@ int camal_create(int device_id, int n_members, const int* kernel_sizes, int prec
 }
 
 int camal_create_arch(int device_id, int n_members, const int* kernel_sizes, int precision, int arch, camal_ctx** out) {
+    return camal_create_widths(device_id, n_members, kernel_sizes, precision, arch, C1, out);
+}
+
+size_t camal_member_blob_floats_widths(int kernel_size, int arch, int mid_channels) {
+    if (!mid_supported(mid_channels) || (arch != CAMAL_ARCH_CAMAL && arch != CAMAL_ARCH_RESNET)) return 0;
+    return blob_floats(kernel_size, arch, mid_channels);
+}
+
+int camal_create_widths(int device_id, int n_members, const int* kernel_sizes, int precision, int arch, int mid_channels,
+                        camal_ctx** out) {
     if (!out || !kernel_sizes) return fail(CAMAL_ERR_ARG, "null argument");
+    if (!mid_supported(mid_channels)) return fail(CAMAL_ERR_ARG, "mid_channels must be 32, 64 or 128");
+    if (mid_channels != C1 && precision != CAMAL_FP32)
+        return fail(CAMAL_ERR_ARG, "mid_channels other than 64 run in fp32 (the bf16 kernels are built for the widths CamAL.eval instantiates)");
     if (arch != CAMAL_ARCH_CAMAL && arch != CAMAL_ARCH_RESNET) return fail(CAMAL_ERR_ARG, "arch must be 0 (CamALResNet) or 1 (ResNet)");
     if (arch == CAMAL_ARCH_RESNET)
         for (int e = 0; e < n_members; ++e)
@@ -605,7 +664,7 @@ int camal_create_arch(int device_id, int n_members, const int* kernel_sizes, int
     if (device_id < 0 || device_id >= ndev) return fail(CAMAL_ERR_ARG, "no such device");
     HIP_TRY(hipSetDevice(device_id));
     camal_ctx* c = new camal_ctx();
-    c->device = device_id; c->E = n_members; c->precision = precision; c->arch = arch;
+    c->device = device_id; c->E = n_members; c->precision = precision; c->arch = arch; c->mid = mid_channels;
     // fused blocks pay 8 halo columns per tile: a win where the per-layer path is bandwidth/latency
     // bound (bf16), a 6 % loss of MFMA work where it is already MFMA-bound (fp32, 128-column tiles)
     c->fused = precision == CAMAL_BF16;
@@ -616,7 +675,7 @@ int camal_create_arch(int device_id, int n_members, const int* kernel_sizes, int
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
     c->m.resize(n_members);
     for (int e = 0; e < n_members; ++e) c->m[e].k = kernel_sizes[e];
-    if (dev_alloc(c, (void**)&c->zero_row, 512) || hipMemset(c->zero_row, 0, 512) != hipSuccess) {
+    if (dev_alloc(c, (void**)&c->zero_row, 1024) || hipMemset(c->zero_row, 0, 1024) != hipSuccess) {
         camal_destroy(c);
         return fail(CAMAL_ERR_HIP, "allocating the zero row failed");
     }
@@ -663,16 +722,17 @@ int camal_set_member_weights(camal_ctx* c, int member, const float* f, size_t n_
     if (member < 0 || member >= c->E) return fail(CAMAL_ERR_ARG, "member index out of range");
     Member& m = c->m[member];
     if (m.loaded) return fail(CAMAL_ERR_STATE, "member weights already set (create a new context to replace them)");
-    if (n_floats != blob_floats(m.k, c->arch))
-        return fail(CAMAL_ERR_ARG, "blob has " + std::to_string(n_floats) + " floats, expected " + std::to_string(blob_floats(m.k, c->arch)));
+    if (n_floats != blob_floats(m.k, c->arch, c->mid))
+        return fail(CAMAL_ERR_ARG, "blob has " + std::to_string(n_floats) + " floats, expected " + std::to_string(blob_floats(m.k, c->arch, c->mid)));
+    const int C1 = c->mid, C2 = 2 * c->mid;  // this context's widths (shadow the defaults)
     HIP_TRY(hipSetDevice(c->device));
     const float* p = f;
     int r;
     for (int i = 0; i < 9; ++i) {
-        const int cin = kConvs[i].cin, cout = kConvs[i].cout, ks = conv_ks(c->arch, i, m.k);
+        const int cin = conv_shape(i, c->mid).cin, cout = conv_shape(i, c->mid).cout, ks = conv_ks(c->arch, i, m.k);
         const float* w = p; p += (size_t)cout * cin * ks;
         const float* b = p; p += cout;
-        if (i == 0) {  // stem: [64][1][k] -> [k][64]
+        if (i == 0) {  // stem: [C1][1][k] -> [k][C1]
             std::vector<float> t((size_t)ks * C1);
             for (int co = 0; co < C1; ++co)
                 for (int j = 0; j < ks; ++j) t[(size_t)j * C1 + co] = w[(size_t)co * ks + j];

@@ -117,16 +117,19 @@ __device__ __forceinline__ void load4(const __bf16* p, float (&v)[4]) {
 // Stem: the Cin = 1 layers of block 1 on the VALU (K = k <= 63 is not MFMA-shaped).
 //   a1[t][co] = relu(b'[co] + sum_j w'[co][j] * x[clamp(t + j - k/2)])   (camal_resnet.py:14, ConvBlock 0)
 //   r1[t][co] = wr'[co] * x[t] + br'[co]                                  (residual, :51-54)
-// One workgroup = 64 timesteps x 64 channels; thread = 4 channels x 4 timesteps.
+// One workgroup = 64 timesteps x C channels (C = mid_channels: 64, or 32 / 128); thread = 4 channels x (C / 16)
+// timesteps.
 // ---------------------------------------------------------------------------------------
-template <typename DT>
+template <typename DT, int C = 64>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x,      // [B][L]
-                                                   const float* __restrict__ w,      // [ks][64]
-                                                   const float* __restrict__ bias,   // [64]
-                                                   const float* __restrict__ wr,     // [64]
-                                                   const float* __restrict__ br,     // [64]
-                                                   DT* __restrict__ a1, DT* __restrict__ r1,  // [B][L][64]
+                                                   const float* __restrict__ w,      // [ks][C]
+                                                   const float* __restrict__ bias,   // [C]
+                                                   const float* __restrict__ wr,     // [C]
+                                                   const float* __restrict__ br,     // [C]
+                                                   DT* __restrict__ a1, DT* __restrict__ r1,  // [B][L][C]
                                                    int L, int ks, bool zero_pad = false) {
+    constexpr int CG = C / 4, TQ = 256 / CG, NQ = 64 / TQ;  // channel groups, time slots, timesteps per thread
+    static_assert(CG * TQ == 256 && NQ * TQ == 64 && NQ >= 1, "C must be 16 .. 256, a power of two");
     __shared__ float xs[64 + 64];
     const int b = blockIdx.y, t0 = blockIdx.x * 64, pad = ks >> 1;
     const float* xb = x + (size_t)b * L;
@@ -137,31 +140,31 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
         xs[i] = (zero_pad && pc != p) ? 0.f : xb[pc];
     }
     __syncthreads();
-    const int cg = threadIdx.x & 15, tq = threadIdx.x >> 4;  // 16 channel groups x 16 time slots
-    float acc[4][4];
+    const int cg = threadIdx.x % CG, tq = threadIdx.x / CG;
+    float acc[NQ][4];
     float bv[4], wrv[4], brv[4];
     load4(bias + 4 * cg, bv); load4(wr + 4 * cg, wrv); load4(br + 4 * cg, brv);
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[q][c] = bv[c];
     for (int j = 0; j < ks; ++j) {
         float wv[4];
-        load4(w + j * 64 + 4 * cg, wv);
+        load4(w + j * C + 4 * cg, wv);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float xv = xs[tq + 16 * q + j];
+        for (int q = 0; q < NQ; ++q) {
+            float xv = xs[tq + TQ * q + j];
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[q][c] = fmaf(wv[c], xv, acc[q][c]);
         }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        int t = t0 + tq + 16 * q;
+    for (int q = 0; q < NQ; ++q) {
+        int t = t0 + tq + TQ * q;
         if (t < L) {
-            size_t o = ((size_t)b * L + t) * 64 + 4 * cg;
+            size_t o = ((size_t)b * L + t) * C + 4 * cg;
             store4(a1 + o, fmaxf(acc[q][0], 0.f), fmaxf(acc[q][1], 0.f), fmaxf(acc[q][2], 0.f), fmaxf(acc[q][3], 0.f));
-            float xv = xs[tq + 16 * q + pad];
+            float xv = xs[tq + TQ * q + pad];
             store4(r1 + o, fmaf(wrv[0], xv, brv[0]), fmaf(wrv[1], xv, brv[1]), fmaf(wrv[2], xv, brv[2]),
                    fmaf(wrv[3], xv, brv[3]));
         }
@@ -468,7 +471,7 @@ __global__ __launch_bounds__((NWC + 1) * 64) void conv_kernel(const DT* __restri
                                                             float* __restrict__ cmax) {
     using G = ConvGeom<DT, CIN, COUT, NT, NWC>;
     constexpr int RB = G::RB, CPR = G::CPR, NCP = G::NCP, MT = G::MT, TN = G::TN;
-    static_assert(MT == 2 || MT == 4, "COUT must be 64 or 128");
+    static_assert((MT == 1 || MT == 2 || MT == 4 || MT == 8) && NWC % MT == 0, "COUT is 32, 64, 128 or 256, one 32-channel tile per wave");
     extern __shared__ __attribute__((aligned(1024))) char lds[];
 
     const int lane = threadIdx.x & 63;

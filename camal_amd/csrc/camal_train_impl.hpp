@@ -21,7 +21,8 @@ struct TLayout {
     size_t wfc = 0, bfc = 0, n_params = 0, n_running = 0;
 };
 
-TLayout make_layout(int k, int arch = CAMAL_ARCH_CAMAL) {
+TLayout make_layout(int k, int arch = CAMAL_ARCH_CAMAL, int mid = C1) {
+    const int C1 = mid, C2 = 2 * mid;  // this model's widths (shadow the defaults)
     TLayout t;
     size_t p = 0, r = 0;
     int zi = 0;
@@ -37,7 +38,7 @@ TLayout make_layout(int k, int arch = CAMAL_ARCH_CAMAL) {
     };
     for (int b = 0; b < 3; ++b) {
         for (int i = 0; i < 3; ++i) {
-            const ConvShape& c = kConvs[3 * b + i];
+            const ConvShape c = conv_shape(3 * b + i, mid);
             add(t.conv[3 * b + i], c.cin, c.cout, conv_ks(arch, 3 * b + i, k));
         }
         if (b == 0) add(t.res[0], 1, C1, 1);
@@ -55,6 +56,9 @@ TLayout make_layout(int k, int arch = CAMAL_ARCH_CAMAL) {
 struct camal_trainer {
     int device = 0, k = 0, maxB = 0, maxL = 0, num_cu = 256;
     float grad_scale = 1.f;         // camal_trainer_set_grad_scale
+    int mid = C1;                   // mid_channels (widths 1 -> mid -> 2 mid -> 2 mid): 64, or 32 / 128
+    int c1() const { return mid; }
+    int c2() const { return 2 * mid; }
     int arch = CAMAL_ARCH_CAMAL;    // CAMAL_ARCH_RESNET: kernels 7/5/3 and zeros outside the window (classifiers/resnet.py)
     bool zpad() const { return arch == CAMAL_ARCH_RESNET; }
     size_t lds_per_cu = 160 * 1024;
@@ -63,7 +67,7 @@ struct camal_trainer {
     // activations: z (pre-BN conv outputs) and a (post BN/ReLU, block outputs) per layer slot
     float* z[11] = {nullptr};
     float* act[9] = {nullptr};      // a0,a1,out1, a3,a4,out2, a6,a7,out3
-    float *mean = nullptr, *invstd = nullptr, *s1 = nullptr, *s2 = nullptr;  // [11][128], [128]
+    float *mean = nullptr, *invstd = nullptr, *s1 = nullptr, *s2 = nullptr;  // [11][256], [256]
     double* partial = nullptr;
     float* wpack[9] = {nullptr};    // forward packing of conv 1..8 (index = conv idx), [0] unused
     float* wpack_res2 = nullptr;
@@ -75,7 +79,7 @@ struct camal_trainer {
     float* stem_part = nullptr;
     float *pooled = nullptr, *dpool = nullptr, *logits = nullptr, *dlogits = nullptr, *loss = nullptr;
     int* correct = nullptr;
-    float* zeros = nullptr;         // 128 zeros: zero bias for dgrad and the zero row of its padding
+    float* zeros = nullptr;         // 256 zeros: zero bias for dgrad and the zero row of its padding
 };
 
 namespace {
@@ -130,15 +134,33 @@ int t_pack_all(camal_trainer* t, hipStream_t s, const float* params, bool backwa
     return 0;
 }
 
-// forward conv of layer l (cin >= 64): pack weights, z = conv(in) + bias
+// (cin, cout) pairs of the MFMA layers for the supported mid_channels (32, 64, 128), forward and adjoint direction
+template <typename F>
+int dispatch_cc(int cin, int cout, F&& f) {
+#define CAMAL_CC(A, B) if (cin == A && cout == B) return f(std::integral_constant<int, A>(), std::integral_constant<int, B>());
+    CAMAL_CC(32, 32) CAMAL_CC(32, 64) CAMAL_CC(64, 32) CAMAL_CC(64, 64) CAMAL_CC(64, 128) CAMAL_CC(128, 64)
+    CAMAL_CC(128, 128) CAMAL_CC(128, 256) CAMAL_CC(256, 128) CAMAL_CC(256, 256)
+#undef CAMAL_CC
+    return fail(CAMAL_ERR_STATE, "no kernel for this channel pair");
+}
+
+template <typename F>
+int dispatch_c(int c, F&& f) {
+#define CAMAL_C(A) if (c == A) return f(std::integral_constant<int, A>());
+    CAMAL_C(32) CAMAL_C(64) CAMAL_C(128) CAMAL_C(256)
+#undef CAMAL_C
+    return fail(CAMAL_ERR_STATE, "no kernel for this channel count");
+}
+
+// forward conv of layer l (cin >= 32): z = conv(in) + bias
 int t_conv_fwd(camal_trainer* t, hipStream_t s, const TLayer& l, const float* params, float* wpack, const float* in,
                float* zout, int B, int L) {
     const float* bias = params + l.b;
     const int pad = l.ks >> 1;
     const float* zr = t->zpad() ? t->zeros : nullptr;  // what the layer reads outside the window
-    if (l.cin == C1 && l.cout == C1) return t_conv<C1, C1, false>(t, s, wpack, bias, l.ks, in, nullptr, zout, B, L, L, pad, zr);
-    if (l.cin == C1 && l.cout == C2) return t_conv<C1, C2, false>(t, s, wpack, bias, l.ks, in, nullptr, zout, B, L, L, pad, zr);
-    return t_conv<C2, C2, false>(t, s, wpack, bias, l.ks, in, nullptr, zout, B, L, L, pad, zr);
+    return dispatch_cc(l.cin, l.cout, [&](auto ci, auto co) {
+        return t_conv<decltype(ci)::value, decltype(co)::value, false>(t, s, wpack, bias, l.ks, in, nullptr, zout, B, L, L, pad, zr);
+    });
 }
 
 template <int C>
@@ -147,24 +169,23 @@ int t_bn_stats(camal_trainer* t, hipStream_t s, const float* z, int N, const TLa
     const int nb = (N + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK;
     hipLaunchKernelGGL(bn_stats_partial_kernel<C>, dim3(nb), dim3(256), 0, s, z, N, t->partial);
     hipLaunchKernelGGL(bn_stats_final_kernel<C>, dim3(C / BN_FINAL_CPB), dim3(BN_FINAL_THREADS), 0, s, t->partial, nb, N, eps, momentum,
-                       t->mean + l.zi * 128, t->invstd + l.zi * 128, running ? running + l.rm : nullptr,
+                       t->mean + l.zi * 256, t->invstd + l.zi * 256, running ? running + l.rm : nullptr,
                        running ? running + l.rv : nullptr);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 int t_bn_stats_any(camal_trainer* t, hipStream_t s, const float* z, int N, const TLayer& l, float momentum, float* running) {
-    return l.cout == C1 ? t_bn_stats<C1>(t, s, z, N, l, 1e-5f, momentum, running)
-                        : t_bn_stats<C2>(t, s, z, N, l, 1e-5f, momentum, running);
+    return dispatch_c(l.cout, [&](auto c) { return t_bn_stats<decltype(c)::value>(t, s, z, N, l, 1e-5f, momentum, running); });
 }
 
 template <int C, bool RELU, bool HAS_RES>
 int t_bn_apply(camal_trainer* t, hipStream_t s, const float* params, const TLayer& l, const float* z, const TLayer* lr,
                const float* zr, float* out, int N) {
     const size_t n4 = (size_t)N * (C / 4);
-    hipLaunchKernelGGL((bn_apply_kernel<C, RELU, HAS_RES>), dim3(gs_blocks(n4)), dim3(256), 0, s, z, t->mean + l.zi * 128,
-                       t->invstd + l.zi * 128, params + l.g, params + l.be, zr, lr ? t->mean + lr->zi * 128 : nullptr,
-                       lr ? t->invstd + lr->zi * 128 : nullptr, lr ? params + lr->g : nullptr,
+    hipLaunchKernelGGL((bn_apply_kernel<C, RELU, HAS_RES>), dim3(gs_blocks(n4)), dim3(256), 0, s, z, t->mean + l.zi * 256,
+                       t->invstd + l.zi * 256, params + l.g, params + l.be, zr, lr ? t->mean + lr->zi * 256 : nullptr,
+                       lr ? t->invstd + lr->zi * 256 : nullptr, lr ? params + lr->g : nullptr,
                        lr ? params + lr->be : nullptr, out, n4);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -175,8 +196,8 @@ template <int C, bool RELU, bool BCAST>
 int t_bn_bwd(camal_trainer* t, hipStream_t s, const float* params, float* grads, const TLayer& l, const float* da,
              const float* z, float* dz, int N, int L) {
     const int nb = (N + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK;
-    const float* mean = t->mean + l.zi * 128;
-    const float* invstd = t->invstd + l.zi * 128;
+    const float* mean = t->mean + l.zi * 256;
+    const float* invstd = t->invstd + l.zi * 256;
     const float inv_len = 1.f / (float)L;
     hipLaunchKernelGGL((bn_bwd_partial_kernel<C, RELU, BCAST>), dim3(nb), dim3(256), 0, s, da, z, mean, invstd,
                        params + l.g, params + l.be, N, L, inv_len, t->partial);
@@ -212,10 +233,11 @@ int t_wgrad(camal_trainer* t, hipStream_t s, const TLayer& l, const float* dz, c
         }
         return 0;
     };
-    int rc;
-    if (l.cin == C1 && l.cout == C1) rc = launch(std::integral_constant<int, C1>(), std::integral_constant<int, C1>());
-    else if (l.cin == C1 && l.cout == C2) rc = launch(std::integral_constant<int, C1>(), std::integral_constant<int, C2>());
-    else rc = launch(std::integral_constant<int, C2>(), std::integral_constant<int, C2>());
+    int rc = fail(CAMAL_ERR_STATE, "no weight-gradient kernel for this channel pair");
+#define CAMAL_WG_CC(A, B) if (l.cin == A && l.cout == B) rc = launch(std::integral_constant<int, A>(), std::integral_constant<int, B>());
+    CAMAL_WG_CC(32, 32) CAMAL_WG_CC(32, 64) CAMAL_WG_CC(64, 64) CAMAL_WG_CC(64, 128) CAMAL_WG_CC(128, 128)
+    CAMAL_WG_CC(128, 256) CAMAL_WG_CC(256, 256)
+#undef CAMAL_WG_CC
     if (rc) return rc;
     const int total = l.cout * l.cin * l.ks;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total / 4 + 63) / 64), dim3(256), 0, s, t->wg_part, nsplit, l.cout, l.cin,
@@ -226,9 +248,17 @@ int t_wgrad(camal_trainer* t, hipStream_t s, const TLayer& l, const float* dz, c
 
 int t_stem_wgrad(camal_trainer* t, hipStream_t s, const TLayer& l, const float* dz, const float* x, float* grads, int B, int L) {
     const int nseg = stem_nseg(L);
-    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(B, nseg), dim3(256), 0, s, dz, x, t->stem_part, L, l.ks, t->zpad());
-    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(l.ks), dim3(256), 0, s, t->stem_part, B * nseg, l.ks, grads + l.w,
-                       grads + l.b);
+    if (int r = dispatch_c(l.cout, [&](auto c) {
+            constexpr int C = decltype(c)::value;
+            if constexpr (C <= 128) {
+                hipLaunchKernelGGL(stem_wgrad_kernel<C>, dim3(B, nseg), dim3(256), 0, s, dz, x, t->stem_part, L, l.ks, t->zpad());
+                hipLaunchKernelGGL(stem_wgrad_reduce_kernel<C>, dim3(l.ks), dim3(256), 0, s, t->stem_part, B * nseg, l.ks,
+                                   grads + l.w, grads + l.b);
+                return 0;
+            } else {
+                return fail(CAMAL_ERR_STATE, "no stem kernel for this width");
+            }
+        })) return r;
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -238,21 +268,21 @@ int t_stem_wgrad(camal_trainer* t, hipStream_t s, const TLayer& l, const float* 
 int t_dgrad(camal_trainer* t, hipStream_t s, const TLayer& l, const float* params, float* wflip, const float* dz,
             float* dx, int B, int L) {
     const int pad = l.ks >> 1, Lp = L + 2 * pad;
-    int r;
     if (t->zpad()) {
         // zero padding has no fold: the adjoint is the "same" correlation with the flipped, transposed weights,
         // dz read as zeros outside the window (ks odd: ks - 1 - pad = pad)
-        if (l.cin == C1 && l.cout == C1) return t_conv<C1, C1, false>(t, s, wflip, t->zeros, l.ks, dz, nullptr, dx, B, L, L, pad, t->zeros);
-        if (l.cin == C1 && l.cout == C2) return t_conv<C2, C1, false>(t, s, wflip, t->zeros, l.ks, dz, nullptr, dx, B, L, L, pad, t->zeros);
-        return t_conv<C2, C2, false>(t, s, wflip, t->zeros, l.ks, dz, nullptr, dx, B, L, L, pad, t->zeros);
+        return dispatch_cc(l.cout, l.cin, [&](auto ci, auto co) {
+            return t_conv<decltype(ci)::value, decltype(co)::value, false>(t, s, wflip, t->zeros, l.ks, dz, nullptr, dx, B, L, L, pad, t->zeros);
+        });
     }
-    if (l.cin == C1 && l.cout == C1) r = t_conv<C1, C1, false>(t, s, wflip, t->zeros, l.ks, dz, nullptr, t->gXP, B, Lp, L, 2 * pad, t->zeros);
-    else if (l.cin == C1 && l.cout == C2) r = t_conv<C2, C1, false>(t, s, wflip, t->zeros, l.ks, dz, nullptr, t->gXP, B, Lp, L, 2 * pad, t->zeros);
-    else r = t_conv<C2, C2, false>(t, s, wflip, t->zeros, l.ks, dz, nullptr, t->gXP, B, Lp, L, 2 * pad, t->zeros);
-    if (r) return r;
+    if (int r = dispatch_cc(l.cout, l.cin, [&](auto ci, auto co) {
+            return t_conv<decltype(ci)::value, decltype(co)::value, false>(t, s, wflip, t->zeros, l.ks, dz, nullptr, t->gXP, B, Lp, L, 2 * pad, t->zeros);
+        })) return r;
     const size_t n4 = (size_t)B * L * (l.cin / 4);
-    if (l.cin == C1) hipLaunchKernelGGL(fold_edges_kernel<C1>, dim3(gs_blocks(n4)), dim3(256), 0, s, t->gXP, dx, B, L, pad);
-    else hipLaunchKernelGGL(fold_edges_kernel<C2>, dim3(gs_blocks(n4)), dim3(256), 0, s, t->gXP, dx, B, L, pad);
+    if (int r = dispatch_c(l.cin, [&](auto c) {
+            hipLaunchKernelGGL(fold_edges_kernel<decltype(c)::value>, dim3(gs_blocks(n4)), dim3(256), 0, s, t->gXP, dx, B, L, pad);
+            return 0;
+        })) return r;
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -266,13 +296,27 @@ size_t camal_trainer_param_count_arch(int kernel_size, int arch) {
     return arch == CAMAL_ARCH_CAMAL || arch == CAMAL_ARCH_RESNET ? make_layout(kernel_size, arch).n_params : 0;
 }
 size_t camal_trainer_running_count(void) { return make_layout(7).n_running; }
+size_t camal_trainer_param_count_widths(int kernel_size, int arch, int mid_channels) {
+    if (!mid_supported(mid_channels) || (arch != CAMAL_ARCH_CAMAL && arch != CAMAL_ARCH_RESNET)) return 0;
+    return make_layout(kernel_size, arch, mid_channels).n_params;
+}
+size_t camal_trainer_running_count_widths(int mid_channels) {
+    return mid_supported(mid_channels) ? make_layout(7, CAMAL_ARCH_CAMAL, mid_channels).n_running : 0;
+}
 
 int camal_trainer_create(int device_id, int kernel_size, int max_batch, int max_len, camal_trainer** out) {
     return camal_trainer_create_arch(device_id, kernel_size, max_batch, max_len, CAMAL_ARCH_CAMAL, out);
 }
 
 int camal_trainer_create_arch(int device_id, int kernel_size, int max_batch, int max_len, int arch, camal_trainer** out) {
+    return camal_trainer_create_widths(device_id, kernel_size, max_batch, max_len, arch, C1, out);
+}
+
+int camal_trainer_create_widths(int device_id, int kernel_size, int max_batch, int max_len, int arch, int mid_channels,
+                                camal_trainer** out) {
     if (!out) return fail(CAMAL_ERR_ARG, "null argument");
+    if (!mid_supported(mid_channels)) return fail(CAMAL_ERR_ARG, "mid_channels must be 32, 64 or 128");
+    const int C2 = 2 * mid_channels;  // this model's widest layer (shadows the default)
     if (arch != CAMAL_ARCH_CAMAL && arch != CAMAL_ARCH_RESNET) return fail(CAMAL_ERR_ARG, "arch must be 0 (CamALResNet) or 1 (ResNet)");
     if (arch == CAMAL_ARCH_RESNET && kernel_size != 7) return fail(CAMAL_ERR_ARG, "the ResNet variant has kernel sizes 7, 5, 3: pass 7");
     if (kernel_size < 1 || kernel_size > 63 || !(kernel_size & 1)) return fail(CAMAL_ERR_ARG, "kernel size must be odd and in 1..63");
@@ -283,7 +327,8 @@ int camal_trainer_create_arch(int device_id, int kernel_size, int max_batch, int
     HIP_TRY(hipSetDevice(device_id));
     camal_trainer* t = new camal_trainer();
     t->device = device_id; t->k = kernel_size; t->maxB = max_batch; t->maxL = max_len; t->arch = arch;
-    t->lay = make_layout(kernel_size, arch);
+    t->mid = mid_channels;
+    t->lay = make_layout(kernel_size, arch, mid_channels);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) t->num_cu = prop.multiProcessorCount;
     const size_t N = (size_t)max_batch * max_len;
@@ -295,8 +340,8 @@ int camal_trainer_create_arch(int device_id, int kernel_size, int max_batch, int
     zl[t->lay.res[1].zi] = &t->lay.res[1];
     for (int i = 0; i < 11; ++i) A(&t->z[i], N * zl[i]->cout);
     for (int i = 0; i < 9; ++i) A(&t->act[i], N * t->lay.conv[i].cout);
-    A(&t->mean, 11 * 128); A(&t->invstd, 11 * 128); A(&t->s1, 128); A(&t->s2, 128);
-    if (!r) r = t_alloc(t, (void**)&t->partial, ((N + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK) * 128 * 2 * sizeof(double));
+    A(&t->mean, 11 * 256); A(&t->invstd, 11 * 256); A(&t->s1, 256); A(&t->s2, 256);
+    if (!r) r = t_alloc(t, (void**)&t->partial, ((N + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK) * 256 * 2 * sizeof(double));
     size_t wg_max = 0;
     for (int i = 1; i < 9; ++i) {
         const TLayer& l = t->lay.conv[i];
@@ -315,12 +360,12 @@ int camal_trainer_create_arch(int device_id, int kernel_size, int max_batch, int
     const int pad_max = std::max(kernel_size >> 1, 3);
     A(&t->gA, N * C2); A(&t->gB, N * C2); A(&t->gZ, N * C2); A(&t->gZr, N * C2);
     A(&t->gXP, (size_t)max_batch * (max_len + 2 * pad_max) * C2);
-    A(&t->stem_part, (size_t)max_batch * stem_nseg(max_len) * kernel_size * 64);
-    A(&t->pooled, (size_t)max_batch * 128); A(&t->dpool, (size_t)max_batch * 128);
+    A(&t->stem_part, (size_t)max_batch * stem_nseg(max_len) * kernel_size * mid_channels);
+    A(&t->pooled, (size_t)max_batch * C2); A(&t->dpool, (size_t)max_batch * C2);
     A(&t->logits, (size_t)max_batch * 2); A(&t->dlogits, (size_t)max_batch * 2); A(&t->loss, (size_t)max_batch);
     if (!r) r = t_alloc(t, (void**)&t->correct, (size_t)max_batch * sizeof(int));
-    A(&t->zeros, 128);
-    if (!r && hipMemset(t->zeros, 0, 128 * 4) != hipSuccess) r = fail(CAMAL_ERR_HIP, "hipMemset failed");
+    A(&t->zeros, 256);
+    if (!r && hipMemset(t->zeros, 0, 256 * 4) != hipSuccess) r = fail(CAMAL_ERR_HIP, "hipMemset failed");
     if (r) {
         for (void* p : t->owned) (void)hipFree(p);
         delete t;
@@ -346,13 +391,15 @@ int camal_trainer_set_grad_scale(camal_trainer* t, float scale) {
     return 0;
 }
 
-int camal_train_fwd_bwd(camal_trainer* t, const float* params, float* running, const float* x, const int* y, int B, int L,
-                        float momentum, float* grads, float* logits_out, float* loss_out, int* ncorrect_out, void* stream) {
-    if (!t || !params || !x) return fail(CAMAL_ERR_ARG, "null argument");
-    if (B < 1 || B > t->maxB || L < 1 || L > t->maxL) return fail(CAMAL_ERR_ARG, "B or L exceeds what the trainer was created for");
-    if (grads && (!y || !loss_out || !ncorrect_out)) return fail(CAMAL_ERR_ARG, "labels, loss_out and ncorrect_out are required for the backward pass");
-    HIP_TRY(hipSetDevice(t->device));
-    hipStream_t s = (hipStream_t)stream;
+}  // extern "C"
+
+namespace {
+
+// the step for mid_channels = M (widths 1 -> M -> 2M -> 2M)
+template <int M>
+int train_fwd_bwd_impl(camal_trainer* t, const float* params, float* running, const float* x, const int* y, int B, int L,
+                       float momentum, float* grads, float* logits_out, float* loss_out, int* ncorrect_out, hipStream_t s) {
+    constexpr int C1 = M, C2 = 2 * M;  // shadow the defaults
     const TLayout& Y = t->lay;
     const int N = B * L;
     int r;
@@ -362,7 +409,7 @@ int camal_train_fwd_bwd(camal_trainer* t, const float* params, float* running, c
     {   // block 1 stem: the two Cin = 1 convs on the VALU
         const TLayer& l0 = Y.conv[0];
         const TLayer& lr = Y.res[0];
-        hipLaunchKernelGGL(stem_train_kernel, dim3((L + 63) / 64, B), dim3(256), 0, s, x, params + l0.w, params + l0.b,
+        hipLaunchKernelGGL(stem_train_kernel<C1>, dim3((L + 63) / 64, B), dim3(256), 0, s, x, params + l0.w, params + l0.b,
                            params + lr.w, params + lr.b, t->z[l0.zi], t->z[lr.zi], L, l0.ks, t->zpad());
         HIP_TRY(hipGetLastError());
         if ((r = t_bn_stats_any(t, s, t->z[l0.zi], N, l0, momentum, running))) return r;
@@ -393,12 +440,12 @@ int camal_train_fwd_bwd(camal_trainer* t, const float* params, float* running, c
         }
     }
     // head + loss
-    hipLaunchKernelGGL(head_loss_kernel, dim3(B), dim3(HEAD_LOSS_THREADS), 0, s, t->act[8], params + Y.wfc, params + Y.bfc,
+    hipLaunchKernelGGL(head_loss_kernel<C2>, dim3(B), dim3(HEAD_LOSS_THREADS), 0, s, t->act[8], params + Y.wfc, params + Y.bfc,
                        y ? y : (const int*)t->correct, B, L, t->grad_scale, t->pooled, t->dpool, t->logits, t->dlogits, t->loss, t->correct);
     HIP_TRY(hipGetLastError());
     if (logits_out) HIP_TRY(hipMemcpyAsync(logits_out, t->logits, (size_t)B * 2 * 4, hipMemcpyDeviceToDevice, s));
     if (!grads) return 0;
-    hipLaunchKernelGGL(head_reduce_kernel, dim3(1), dim3(256), 0, s, t->pooled, t->dlogits, t->loss, t->correct, B,
+    hipLaunchKernelGGL(head_reduce_kernel, dim3(1), dim3(256), 0, s, t->pooled, t->dlogits, t->loss, t->correct, B, C2,
                        grads + Y.wfc, grads + Y.bfc, loss_out, ncorrect_out);
     HIP_TRY(hipGetLastError());
 
@@ -438,6 +485,22 @@ int camal_train_fwd_bwd(camal_trainer* t, const float* params, float* running, c
         }
     }
     return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int camal_train_fwd_bwd(camal_trainer* t, const float* params, float* running, const float* x, const int* y, int B, int L,
+                        float momentum, float* grads, float* logits_out, float* loss_out, int* ncorrect_out, void* stream) {
+    if (!t || !params || !x) return fail(CAMAL_ERR_ARG, "null argument");
+    if (B < 1 || B > t->maxB || L < 1 || L > t->maxL) return fail(CAMAL_ERR_ARG, "B or L exceeds what the trainer was created for");
+    if (grads && (!y || !loss_out || !ncorrect_out)) return fail(CAMAL_ERR_ARG, "labels, loss_out and ncorrect_out are required for the backward pass");
+    HIP_TRY(hipSetDevice(t->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (t->mid == 32) return train_fwd_bwd_impl<32>(t, params, running, x, y, B, L, momentum, grads, logits_out, loss_out, ncorrect_out, s);
+    if (t->mid == 128) return train_fwd_bwd_impl<128>(t, params, running, x, y, B, L, momentum, grads, logits_out, loss_out, ncorrect_out, s);
+    return train_fwd_bwd_impl<C1>(t, params, running, x, y, B, L, momentum, grads, logits_out, loss_out, ncorrect_out, s);
 }
 
 int camal_ce_eval(const float* logits, const int* labels, int B, float* loss_out, int* pred_out, void* stream) {

@@ -51,10 +51,12 @@ __global__ void pack_w_kernel(PackJobs jobs) {
 // ---- stem, train mode: raw conv outputs of the two Cin = 1 layers --------------------------
 //   z0[t][co] = b[co] + sum_j w[co][j] x[clamp(t + j - k/2)]     (ConvBlock 0 of block 1)
 //   zr[t][co] = br[co] + wr[co] x[t]                              (residual conv of block 1)
+template <int C>
 __global__ __launch_bounds__(256) void stem_train_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, const float* __restrict__ wr,
                                                          const float* __restrict__ br, float* __restrict__ z0,
                                                          float* __restrict__ zr, int L, int ks, bool zero_pad) {
+    constexpr int CG = C / 4, TQ = 256 / CG, NQ = 64 / TQ;  // as stem_kernel: C = mid_channels
     __shared__ float xs[64 + 64];
     const int b = blockIdx.y, t0 = blockIdx.x * 64, pad = ks >> 1;
     const float* xb = x + (size_t)b * L;
@@ -64,11 +66,11 @@ __global__ __launch_bounds__(256) void stem_train_kernel(const float* __restrict
         xs[i] = (zero_pad && pc != p) ? 0.f : xb[pc];  // zero_pad: classifiers/resnet.py:62
     }
     __syncthreads();
-    const int cg = threadIdx.x & 15, tq = threadIdx.x >> 4;
-    float acc[4][4], bv[4], wrv[4], brv[4];
+    const int cg = threadIdx.x % CG, tq = threadIdx.x / CG;
+    float acc[NQ][4], bv[4], wrv[4], brv[4];
     load4(bias + 4 * cg, bv); load4(wr + 4 * cg, wrv); load4(br + 4 * cg, brv);
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[q][c] = bv[c];
     for (int j = 0; j < ks; ++j) {
@@ -76,19 +78,19 @@ __global__ __launch_bounds__(256) void stem_train_kernel(const float* __restrict
 #pragma unroll
         for (int c = 0; c < 4; ++c) wv[c] = w[(4 * cg + c) * ks + j];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float xv = xs[tq + 16 * q + j];
+        for (int q = 0; q < NQ; ++q) {
+            const float xv = xs[tq + TQ * q + j];
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[q][c] = fmaf(wv[c], xv, acc[q][c]);
         }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int t = t0 + tq + 16 * q;
+    for (int q = 0; q < NQ; ++q) {
+        const int t = t0 + tq + TQ * q;
         if (t < L) {
-            const size_t o = ((size_t)b * L + t) * 64 + 4 * cg;
+            const size_t o = ((size_t)b * L + t) * C + 4 * cg;
             store4(z0 + o, acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
-            const float xv = xs[tq + 16 * q + pad];
+            const float xv = xs[tq + TQ * q + pad];
             store4(zr + o, fmaf(wrv[0], xv, brv[0]), fmaf(wrv[1], xv, brv[1]), fmaf(wrv[2], xv, brv[2]),
                    fmaf(wrv[3], xv, brv[3]));
         }
@@ -318,35 +320,36 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 // dlogits = grad_scale * (p - onehot) / B; dpool = W^T dlogits.  grad_scale: 1, or this rank's share b / B_global of a
 // data-parallel step's batch (every gradient of the backward pass is linear in dlogits).
 #define HEAD_LOSS_THREADS 1024
-__global__ __launch_bounds__(HEAD_LOSS_THREADS) void head_loss_kernel(const float* __restrict__ feat /*[B][L][128]*/,
+template <int C>  // C = 2 mid_channels: the feature width the head sees
+__global__ __launch_bounds__(HEAD_LOSS_THREADS) void head_loss_kernel(const float* __restrict__ feat /*[B][L][C]*/,
                                                         const float* __restrict__ wfc, const float* __restrict__ bfc,
                                                         const int* __restrict__ labels, int B, int L, float grad_scale,
-                                                        float* __restrict__ pooled /*[B][128]*/,
-                                                        float* __restrict__ dpool /*[B][128]*/,
+                                                        float* __restrict__ pooled /*[B][C]*/,
+                                                        float* __restrict__ dpool /*[B][C]*/,
                                                         float* __restrict__ logits /*[B][2]*/,
                                                         float* __restrict__ dlogits /*[B][2]*/,
                                                         float* __restrict__ loss /*[B]*/, int* __restrict__ correct) {
     __shared__ float sp[HEAD_LOSS_THREADS];
     __shared__ float sl[4];
-    constexpr int TG = HEAD_LOSS_THREADS / 128;  // time groups per channel
-    const int b = blockIdx.x, c = threadIdx.x & 127, tg = threadIdx.x >> 7;
-    const float* f = feat + (size_t)b * L * 128;
+    constexpr int TG = HEAD_LOSS_THREADS / C;  // time groups per channel
+    const int b = blockIdx.x, c = threadIdx.x % C, tg = threadIdx.x / C;
+    const float* f = feat + (size_t)b * L * C;
     float s = 0.f;
 #pragma unroll 4
-    for (int t = tg; t < L; t += TG) s += f[(size_t)t * 128 + c];
+    for (int t = tg; t < L; t += TG) s += f[(size_t)t * C + c];
     sp[threadIdx.x] = s;
     __syncthreads();
-    if (threadIdx.x < 128) {
+    if (threadIdx.x < C) {
         float a = 0.f;
 #pragma unroll
-        for (int k = 0; k < TG; ++k) a += sp[c + 128 * k];
+        for (int k = 0; k < TG; ++k) a += sp[c + C * k];
         sp[c] = a / (float)L;
     }
     __syncthreads();
-    if (threadIdx.x < 128) pooled[(size_t)b * 128 + c] = sp[c];
+    if (threadIdx.x < C) pooled[(size_t)b * C + c] = sp[c];
     if (threadIdx.x < 2) {
         float a = 0.f;
-        for (int k = 0; k < 128; ++k) a = fmaf(wfc[threadIdx.x * 128 + k], sp[k], a);
+        for (int k = 0; k < C; ++k) a = fmaf(wfc[threadIdx.x * C + k], sp[k], a);
         sl[threadIdx.x] = a + bfc[threadIdx.x];
     }
     __syncthreads();
@@ -365,20 +368,22 @@ __global__ __launch_bounds__(HEAD_LOSS_THREADS) void head_loss_kernel(const floa
         sl[2] = d0; sl[3] = d1;
     }
     __syncthreads();
-    if (threadIdx.x < 128) dpool[(size_t)b * 128 + c] = wfc[c] * sl[2] + wfc[128 + c] * sl[3];
+    if (threadIdx.x < C) dpool[(size_t)b * C + c] = wfc[c] * sl[2] + wfc[C + c] * sl[3];
 }
 
 // grads of the head and the batch loss / accuracy, fixed order over the batch (one workgroup)
 __global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restrict__ pooled, const float* __restrict__ dlogits,
                                                           const float* __restrict__ loss, const int* __restrict__ correct,
-                                                          int B, float* __restrict__ dwfc /*[2][128]*/,
+                                                          int B, int C, float* __restrict__ dwfc /*[2][C]*/,
                                                           float* __restrict__ dbfc /*[2]*/, float* __restrict__ loss_out,
                                                           int* __restrict__ ncorrect_out) {
-    const int k = threadIdx.x >> 7, c = threadIdx.x & 127;
-    float a = 0.f;
+    for (int idx = threadIdx.x; idx < 2 * C; idx += 256) {  // C = 128: one element per thread, as before
+        const int k = idx / C, c = idx - k * C;
+        float a = 0.f;
 #pragma unroll 8
-    for (int b = 0; b < B; ++b) a = fmaf(dlogits[2 * b + k], pooled[(size_t)b * 128 + c], a);
-    dwfc[k * 128 + c] = a;
+        for (int b = 0; b < B; ++b) a = fmaf(dlogits[2 * b + k], pooled[(size_t)b * C + c], a);
+        dwfc[k * C + c] = a;
+    }
     // bias gradient, loss and accuracy: wave 0, lane l takes windows l, l + 64, ..., then a fixed xor tree (one lane
     // walking the batch alone was 40 us of dependent loads)
     if (threadIdx.x < 64) {
@@ -455,10 +460,14 @@ __global__ __launch_bounds__(256) void fold_edges_kernel(const float* __restrict
 
 // NTAP (taps of this workgroup's group) is a template parameter: with a run-time count every MFMA sat behind its
 // own branch, LDS read and lgkmcnt(0) (the kernel ran at 0.32 of the fp32 peak).
+// timesteps per staged tile: 64, or 32 for 256 out-channels (the dz tile must fit the 64 KiB of static LDS)
+template <int COUT> struct WgTT { static constexpr int V = COUT > 128 ? 32 : WG_TT; };
+
 template <int CIN, int COUT, int NTAP>
 __device__ __forceinline__ void wgrad_body(float (*s_dz)[COUT], float (*s_a)[32], const float* __restrict__ dz,
                                            const float* __restrict__ ain, float* __restrict__ part, int B, int L, int ks,
                                            int windows_per_split, int j0, bool zero_pad) {
+    constexpr int TT = WgTT<COUT>::V;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int ci0 = blockIdx.x * 32;
@@ -474,9 +483,9 @@ __device__ __forceinline__ void wgrad_body(float (*s_dz)[COUT], float (*s_a)[32]
     // The next tile's rows travel from global memory into registers while this tile's MFMAs run (one LDS copy of
     // each tile: the waves of the CU's other workgroup cover the short register -> LDS phase).
     constexpr int NTH = COUT * 2;
-    constexpr int DZ_PER = WG_TT * (COUT / 4) / NTH;                  // = 8 float4 of dz per lane
-    constexpr int A_Q = (WG_TT + NTAP - 1) * 8, A_PER = (A_Q + NTH - 1) / NTH;
-    static_assert(DZ_PER * NTH == WG_TT * (COUT / 4), "dz tile divides over the workgroup");
+    constexpr int DZ_PER = TT * (COUT / 4) / NTH;                  // = 8 float4 of dz per lane
+    constexpr int A_Q = (TT + NTAP - 1) * 8, A_PER = (A_Q + NTH - 1) / NTH;
+    static_assert(DZ_PER * NTH == TT * (COUT / 4), "dz tile divides over the workgroup");
     float4 rdz[DZ_PER], ra[A_PER];
     auto fetch = [&](int b, int t0) {
         // dz rows t0 .. t0+TT-1 (zeros past L), all COUT channels
@@ -514,14 +523,14 @@ __device__ __forceinline__ void wgrad_body(float (*s_dz)[COUT], float (*s_a)[32]
     };
     if (b0 < b1) fetch(b0, 0);
     for (int b = b0; b < b1; ++b) {
-        for (int t0 = 0; t0 < L; t0 += WG_TT) {
+        for (int t0 = 0; t0 < L; t0 += TT) {
             __syncthreads();
             stash();
             __syncthreads();
-            if (t0 + WG_TT < L) fetch(b, t0 + WG_TT);
+            if (t0 + TT < L) fetch(b, t0 + TT);
             else if (b + 1 < b1) fetch(b + 1, 0);
 #pragma unroll 16
-            for (int s = 0; s < WG_TT / 2; ++s) {
+            for (int s = 0; s < TT / 2; ++s) {
                 const float av = s_dz[2 * s + h][32 * wave + i];
 #pragma unroll
                 for (int j = 0; j < NTAP; ++j)
@@ -546,8 +555,8 @@ template <int CIN, int COUT, int NHI>
 __global__ __launch_bounds__(COUT * 2) void wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ ain,
                                                          float* __restrict__ part, int B, int L, int ks,
                                                          int windows_per_split, int n_hi, bool zero_pad) {
-    __shared__ float s_dz[WG_TT][COUT];
-    __shared__ float s_a[WG_TT + WG_TAPS][32];
+    __shared__ float s_dz[WgTT<COUT>::V][COUT];
+    __shared__ float s_a[WgTT<COUT>::V + WG_TAPS][32];
     const int y = blockIdx.y;
     if (y < n_hi) {
         wgrad_body<CIN, COUT, NHI>(s_dz, s_a, dz, ain, part, B, L, ks, windows_per_split, y * NHI, zero_pad);
@@ -595,14 +604,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 #define STEM_SEG_LEN 128
 __host__ __device__ inline int stem_nseg(int L) { return (L + STEM_SEG_LEN - 1) / STEM_SEG_LEN; }
 
+template <int C>  // C = mid_channels out-channels; 256 / C phases walk the segment's timesteps
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                          float* __restrict__ part, int L, int ks, bool zero_pad) {
-    __shared__ float red[4][64];
+    constexpr int PH = 256 / C;
+    __shared__ float red[PH][C];
     __shared__ float xs[STEM_SEG_LEN + 64 + 8];
-    const int b = blockIdx.x, seg = blockIdx.y, co = threadIdx.x & 63, ph = threadIdx.x >> 6, pad = ks >> 1;
+    const int b = blockIdx.x, seg = blockIdx.y, co = threadIdx.x % C, ph = threadIdx.x / C, pad = ks >> 1;
     const int t0 = seg * STEM_SEG_LEN, t1 = min(L, t0 + STEM_SEG_LEN);
     const float* xb = x + (size_t)b * L;
-    const float* dzb = dz + (size_t)b * L * 64;
+    const float* dzb = dz + (size_t)b * L * C;
     // xs[r] = x[clamp(t0 - pad + r)]; the rows past the last tap only meet accumulators that are never stored
     for (int r = threadIdx.x; r < STEM_SEG_LEN + 64 + 8; r += 256) {
         const int p = t0 - pad + r;
@@ -610,14 +621,14 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
         xs[r] = (zero_pad && pc != p) ? 0.f : xb[pc];
     }
     __syncthreads();
-    float* po = part + ((size_t)b * gridDim.y + seg) * ks * 64;
+    float* po = part + ((size_t)b * gridDim.y + seg) * ks * C;
     for (int j0 = 0; j0 < ks; j0 += 8) {
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll 4
-        for (int t = t0 + ph; t < t1; t += 4) {
-            const float d = dzb[(size_t)t * 64 + co];
+        for (int t = t0 + ph; t < t1; t += PH) {
+            const float d = dzb[(size_t)t * C + co];
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = fmaf(d, xs[t - t0 + j0 + j], acc[j]);
         }
@@ -626,24 +637,44 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
             __syncthreads();
             red[ph][co] = acc[j];
             __syncthreads();
-            if (ph == 0 && j0 + j < ks) po[(j0 + j) * 64 + co] = (red[0][co] + red[1][co]) + (red[2][co] + red[3][co]);
+            if (ph == 0 && j0 + j < ks) {
+                float v;
+                if constexpr (PH == 4) v = (red[0][co] + red[1][co]) + (red[2][co] + red[3][co]);  // the order the 64-channel kernel always used
+                else {
+                    v = 0.f;
+#pragma unroll
+                    for (int q = 0; q < PH; ++q) v += red[q][co];
+                }
+                po[(j0 + j) * C + co] = v;
+            }
         }
     }
 }
 
-// grad[co][j] = sum_p part[p][j][co], one workgroup per tap: four lanes per channel walk every fourth partial
+// grad[co][j] = sum_p part[p][j][co], one workgroup per tap: 256 / C lanes per channel walk the partials in strides
 // (independent loads), combined in a fixed order
+template <int C>
 __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ part, int nparts, int ks,
                                                                 float* __restrict__ grad, float* __restrict__ bias_grad) {
-    __shared__ float red[4][64];
-    const int j = blockIdx.x, co = threadIdx.x & 63, g = threadIdx.x >> 6;
+    constexpr int PH = 256 / C;
+    __shared__ float red[PH][C];
+    const int j = blockIdx.x, co = threadIdx.x % C, g = threadIdx.x / C;
     float a = 0.f;
 #pragma unroll 8
-    for (int p = g; p < nparts; p += 4) a += part[((size_t)p * ks + j) * 64 + co];
+    for (int p = g; p < nparts; p += PH) a += part[((size_t)p * ks + j) * C + co];
     red[g][co] = a;
     __syncthreads();
-    if (g == 0) grad[co * ks + j] = (red[0][co] + red[1][co]) + (red[2][co] + red[3][co]);
-    if (g == 1 && j == 0) bias_grad[co] = 0.f;
+    if (g == 0) {
+        float v;
+        if constexpr (PH == 4) v = (red[0][co] + red[1][co]) + (red[2][co] + red[3][co]);
+        else {
+            v = 0.f;
+#pragma unroll
+            for (int q = 0; q < PH; ++q) v += red[q][co];
+        }
+        grad[co * ks + j] = v;
+    }
+    if (g == PH - 1 && j == 0) bias_grad[co] = 0.f;
 }
 
 // ---- AdamW (torch.optim.AdamW defaults: torch_trainer.py:35; decoupled weight decay) -------------------

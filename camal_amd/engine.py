@@ -21,19 +21,15 @@ def folded_blob(sd) -> np.ndarray:
     """
     sd = weights.to_numpy_state_dict(sd)
     k = weights.kernel_size_of(sd)
-    w0 = sd["layers.0.layers.0.layers.0.weight"]
-    if w0.shape[0] != 64 or w0.shape[1] != 1 or sd["linear.weight"].shape != (2, 128):
-        raise NotImplementedError(
-            "the HIP inference path implements the widths CamAL.eval() instantiates "
-            "(in_channels=1, mid_channels=64, nb_class=2; reference core.py:386-390)")
+    mid = mid_channels_of(sd)
     parts = []
-    for prefix, _ci, _co, _k in weights.conv_layers(k, arch=weights.arch_of(sd)):
+    for prefix, _ci, _co, _k in weights.conv_layers(k, mid_channels=mid, arch=weights.arch_of(sd)):
         w, b = weights.fold_conv_bn(
             sd[prefix + ".layers.0.weight"], sd[prefix + ".layers.0.bias"],
             sd[prefix + ".layers.1.weight"], sd[prefix + ".layers.1.bias"],
             sd[prefix + ".layers.1.running_mean"], sd[prefix + ".layers.1.running_var"])
         parts += [w.ravel(), b.ravel()]
-    for prefix, _ci, _co in weights.residual_layers():
+    for prefix, _ci, _co in weights.residual_layers(mid_channels=mid):
         w, b = weights.fold_conv_bn(
             sd[prefix + ".0.weight"], sd[prefix + ".0.bias"],
             sd[prefix + ".1.weight"], sd[prefix + ".1.bias"],
@@ -41,6 +37,21 @@ def folded_blob(sd) -> np.ndarray:
         parts += [w.ravel(), b.ravel()]
     parts += [np.asarray(sd["linear.weight"], np.float32).ravel(), np.asarray(sd["linear.bias"], np.float32).ravel()]
     return np.ascontiguousarray(np.concatenate(parts), dtype=np.float32)
+
+
+SUPPORTED_MID_CHANNELS = (32, 64, 128)
+
+
+def mid_channels_of(sd) -> int:
+    """mid_channels of a state dict (camal_resnet.py:8,14-16), checked against what the library has kernels for:
+    in_channels = 1, nb_class = 2, mid_channels 32 / 64 / 128 (64 is what CamAL.eval() always builds, core.py:386-390)."""
+    w0 = np.asarray(sd["layers.0.layers.0.layers.0.weight"])
+    mid = int(w0.shape[0])
+    if w0.shape[1] != 1 or tuple(np.asarray(sd["linear.weight"]).shape) != (2, 2 * mid) or mid not in SUPPORTED_MID_CHANNELS:
+        raise NotImplementedError(
+            "the HIP path implements in_channels=1, nb_class=2 and mid_channels in (32, 64, 128); "
+            f"got first conv {tuple(w0.shape)}, linear {tuple(np.asarray(sd['linear.weight']).shape)}")
+    return mid
 
 
 def _device_index(device) -> int:
@@ -68,14 +79,19 @@ class Ensemble:
             raise ValueError("the members of one ensemble share one classifier architecture")
         self.arch = archs.pop()
         arch_id = {weights.ARCH_CAMAL: _lib.ARCH_CAMAL, weights.ARCH_RESNET: _lib.ARCH_RESNET}[self.arch]
+        mids = {mid_channels_of(sd) for sd in sds}
+        if len(mids) != 1:
+            raise ValueError("the members of one ensemble share one mid_channels")
+        self.mid_channels = mids.pop()
         self.E = len(sds)
         ks = (C.c_int * self.E)(*self.kernel_sizes)
         h = C.c_void_p()
-        _lib.check(self.lib.camal_create_arch(self.dev_index, self.E, ks, self.precision, arch_id, C.byref(h)))
+        _lib.check(self.lib.camal_create_widths(self.dev_index, self.E, ks, self.precision, arch_id, self.mid_channels,
+                                                C.byref(h)))
         self._h = h
         for e, sd in enumerate(sds):
             blob = folded_blob(sd)
-            assert blob.size == self.lib.camal_member_blob_floats_arch(self.kernel_sizes[e], arch_id)
+            assert blob.size == self.lib.camal_member_blob_floats_widths(self.kernel_sizes[e], arch_id, self.mid_channels)
             _lib.check(self.lib.camal_set_member_weights(
                 self._h, e, blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size))
         if chunk_windows:

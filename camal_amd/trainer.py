@@ -121,19 +121,20 @@ class TrainEngine:
         if d.type != "cuda":
             raise _lib.CamalHipError(f"camal_amd trains on MI355X only (device={device!r}); there is no CPU path.")
         self.device = torch.device("cuda", d.index if d.index is not None else torch.cuda.current_device())
-        if (model.in_channels, model.mid_channels, model.nb_class) != (1, 64, 2):
-            raise NotImplementedError("the HIP training path implements in_channels=1, mid_channels=64, nb_class=2")
+        if (model.in_channels, model.nb_class) != (1, 2) or model.mid_channels not in (32, 64, 128):
+            raise NotImplementedError("the HIP training path implements in_channels=1, nb_class=2, mid_channels in (32, 64, 128)")
         self.k = model.kernel_size
+        self.mid = int(model.mid_channels)
         self.arch = getattr(model, "_arch", weights.ARCH_CAMAL)
         arch_id = {weights.ARCH_CAMAL: _lib.ARCH_CAMAL, weights.ARCH_RESNET: _lib.ARCH_RESNET}[self.arch]
-        self.keys = weights.trainable_keys(self.k, arch=self.arch)
+        self.keys = weights.trainable_keys(self.k, mid_channels=self.mid, arch=self.arch)
         self.bn_prefixes = [k[:-len(".running_mean")] for k in model._params if k.endswith("running_mean")]
-        self.n = int(self.lib.camal_trainer_param_count_arch(self.k, arch_id))
+        self.n = int(self.lib.camal_trainer_param_count_widths(self.k, arch_id, self.mid))
         assert self.n == sum(model._params[k].size for k in self.keys)
-        self.n_running = int(self.lib.camal_trainer_running_count())
+        self.n_running = int(self.lib.camal_trainer_running_count_widths(self.mid))
         h = C.c_void_p()
-        _lib.check(self.lib.camal_trainer_create_arch(self.device.index, self.k, int(max_batch), int(length), arch_id,
-                                                      C.byref(h)))
+        _lib.check(self.lib.camal_trainer_create_widths(self.device.index, self.k, int(max_batch), int(length), arch_id,
+                                                        self.mid, C.byref(h)))
         self._h = h
         self.max_batch, self.length = int(max_batch), int(length)
         with torch.cuda.device(self.device):

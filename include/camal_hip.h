@@ -68,6 +68,14 @@ int camal_destroy(camal_ctx* ctx);
 int camal_create_arch(int device_id, int n_members, const int* kernel_sizes, int precision, int arch, camal_ctx** out);
 size_t camal_member_blob_floats_arch(int kernel_size, int arch); /* 0 for an unknown arch */
 
+/* The same for CamALResNet(mid_channels=...) (camal_resnet.py:8,14-16: widths 1 -> mid -> 2 mid -> 2 mid; what
+ * CamAL.train builds from its resnet_kwargs, core.py:36-38,106).  mid_channels 32, 64 or 128; 64 is camal_create_arch.
+ * Other widths run in fp32, one kernel per ConvBlock (precision must be CAMAL_FP32).  Blob layout as above with 64 /
+ * 128 replaced by mid / 2 mid.                                                                                    */
+int camal_create_widths(int device_id, int n_members, const int* kernel_sizes, int precision, int arch, int mid_channels,
+                        camal_ctx** out);
+size_t camal_member_blob_floats_widths(int kernel_size, int arch, int mid_channels); /* 0 if unsupported */
+
 /* Upload one member's folded weights (HOST pointer, layout above); the library re-lays them
  * out into MFMA fragment order.  Replaces load_state_dict + .to(device) (core.py:391-398). */
 int camal_set_member_weights(camal_ctx* ctx, int member, const float* folded_host, size_t n_floats);
@@ -218,6 +226,11 @@ int camal_trainer_create(int device_id, int kernel_size, int max_batch, int max_
  * model.parameters(), layers read zeros outside the window, so the data gradient needs no edge fold.            */
 int camal_trainer_create_arch(int device_id, int kernel_size, int max_batch, int max_len, int arch, camal_trainer** out);
 size_t camal_trainer_param_count_arch(int kernel_size, int arch); /* 0 for an unknown arch */
+/* The same for mid_channels 32, 64 or 128 (CamAL.train with resnet_kwargs, core.py:36-38,106). */
+int camal_trainer_create_widths(int device_id, int kernel_size, int max_batch, int max_len, int arch, int mid_channels,
+                                camal_trainer** out);
+size_t camal_trainer_param_count_widths(int kernel_size, int arch, int mid_channels); /* 0 if unsupported */
+size_t camal_trainer_running_count_widths(int mid_channels);                          /* 0 if unsupported */
 int camal_trainer_destroy(camal_trainer* t);
 
 /* Data-parallel training (replaces nn.DataParallel, torch_trainer.py:82-90, whose loss is the mean over the

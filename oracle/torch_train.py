@@ -25,7 +25,8 @@ class FunctionalResNet:
         sd = weights.to_numpy_state_dict(sd)
         self.k = weights.kernel_size_of(sd)
         self.arch = weights.arch_of(sd)  # "resnet": classifiers/resnet.py's ResNet, zero "same" padding (:62)
-        self.keys = weights.trainable_keys(self.k, arch=self.arch)
+        self.mid = int(np.asarray(sd["layers.0.layers.0.layers.0.weight"]).shape[0])  # mid_channels (camal_resnet.py:8)
+        self.keys = weights.trainable_keys(self.k, mid_channels=self.mid, arch=self.arch)
         self.p = {k: torch.tensor(np.array(sd[k]), dtype=dtype, requires_grad=k in self.keys)
                   for k in sd if not k.endswith("num_batches_tracked")}
         self.nbt = int(sd["layers.0.layers.0.layers.1.num_batches_tracked"])

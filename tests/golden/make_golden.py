@@ -141,21 +141,21 @@ def run_case(name, data, seed, gain, w_ma=5, gated=False, members=None):
           f"size={os.path.getsize(os.path.join(HERE, name + '.npz')) / 1024:.0f} KB")
 
 
-def train_case(name, k, seed, n, length, batch, epochs, lr=1e-3, arch=weights.ARCH_CAMAL):
+def train_case(name, k, seed, n, length, batch, epochs, lr=1e-3, arch=weights.ARCH_CAMAL, mid=64):
     """Training fixtures from the reference's own classes: one backward pass of CamALResNet in
     train() mode under nn.CrossEntropyLoss (torch_trainer.py:288-291), and `epochs` epochs of
     BasedClassifTrainer.train (AdamW, torch_trainer.py:92-171,273-300) on an unshuffled loader."""
     from src.helpers.torch_trainer import BasedClassifTrainer
     from src.helpers.torch_dataset import TSDataset
     x, y = synth.ideal_windows(n, length, seed=seed)
-    sd0 = weights.make_state_dict(k, seed=seed, head_gain=1.0, arch=arch)
-    keys = weights.trainable_keys(k, arch=arch)
+    sd0 = weights.make_state_dict(k, seed=seed, head_gain=1.0, arch=arch, mid_channels=mid)
+    keys = weights.trainable_keys(k, arch=arch, mid_channels=mid)
     if arch == weights.ARCH_RESNET:  # classifiers/resnet.py's ResNet under the same trainer
         from src.models.camal.classifiers.resnet import ResNet
         assert k == 7
         make_model = ResNet
     else:
-        make_model = lambda: CamALResNet(kernel_size=k)  # noqa: E731
+        make_model = lambda: CamALResNet(kernel_size=k, mid_channels=mid)  # noqa: E731
 
     # (1) one forward/backward on the first batch
     m = make_model()
@@ -173,7 +173,7 @@ def train_case(name, k, seed, n, length, batch, epochs, lr=1e-3, arch=weights.AR
     run_keys = [kk for kk in sd1 if kk.endswith("running_mean") or kk.endswith("running_var")]
     out = dict(
         k=np.array(k), seed=np.array(seed), n=np.array(n), length=np.array(length), batch=np.array(batch),
-        resnet_variant=np.array(arch == weights.ARCH_RESNET),
+        resnet_variant=np.array(arch == weights.ARCH_RESNET), mid=np.array(mid),
         epochs=np.array(epochs), lr=np.array(lr),
         step1_loss=np.array(float(loss)), step1_logits=logits.detach().numpy(),
         step1_grad_norms=np.array([np.linalg.norm(grads[kk].astype(np.float64)) for kk in keys]),
@@ -422,6 +422,53 @@ def resnet_variant_case(name, data, seeds, spread=2.0):
           f"p1 in [{probs[..., 1].min():.3f},{probs[..., 1].max():.3f}]")
 
 
+def width_case(name, mid, kernels, data, seed, spread=2.0):
+    """CamALResNet(kernel_size, mid_channels=mid) (camal_resnet.py:5-19: what CamAL.train builds from its
+    resnet_kwargs, core.py:36-38,106) member by member: forward logits and CAM.run rows from the reference class."""
+    data32 = data.astype(np.float32)
+    n, length = data.shape
+    gains, biases, sds = [], [], []
+    for k in kernels:
+        sd = weights.make_state_dict(k, seed=seed, mid_channels=mid)
+        m = CamALResNet(kernel_size=k, mid_channels=mid)
+        m.load_state_dict(to_torch_sd(sd))
+        m.eval()
+        with torch.no_grad():
+            lg = m(torch.from_numpy(data32[:, None, :])).numpy()
+        d = (lg[:, 1] - lg[:, 0]).astype(np.float64)
+        g = float(np.float32(spread / max(d.std(), 1e-6)))
+        b = (0.0, float(np.float32(-g * np.median(d))))
+        gains.append(g)
+        biases.append(b)
+        sds.append(weights.make_state_dict(k, seed=seed, mid_channels=mid, head_gain=g, head_bias=b))
+    cams = np.zeros((len(kernels), n, length), np.float32)
+    labels = np.zeros((len(kernels), n), np.int32)
+    probs = np.zeros((len(kernels), n, 2), np.float32)
+    logits = np.zeros((len(kernels), n, 2), np.float32)
+    for e, (k, sd) in enumerate(zip(kernels, sds)):
+        m = CamALResNet(kernel_size=k, mid_channels=mid)
+        m.load_state_dict(to_torch_sd(sd))
+        m.eval()
+        cam = CAM(model=m, device="cpu", last_conv_layer=m._modules["layers"][2], fc_layer_name=m._modules["linear"])
+        for i in range(n):
+            c, lab, p = cam.run(instance=data[i], returned_cam_for_label=1)
+            cams[e, i], labels[e, i], probs[e, i] = c, lab, p
+        with torch.no_grad():
+            logits[e] = m(torch.from_numpy(data32[:, None, :])).numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), mid=np.array(mid), members=np.array(kernels), seed=np.array(seed),
+                        head_gain=np.array(gains, np.float64), head_bias=np.array(biases, np.float64), data=data,
+                        cams=cams, labels=labels, probs=probs, logits=logits)
+    print(f"{name}: mid={mid} N={n} L={length} kernels={kernels} labels1={labels.mean():.2f} "
+          f"p1 in [{probs[..., 1].min():.3f},{probs[..., 1].max():.3f}]")
+
+
+def width_cases():
+    width_case("width32_l150", 32, [5, 25], synth.ukdale_windows(6, 150, seed=23), seed=401)
+    width_case("width128_l90", 128, [9], synth.ukdale_windows(4, 90, seed=24), seed=402)
+    train_case("train_width32_k9_l72", k=9, seed=206, n=24, length=72, batch=12, epochs=2, mid=32)
+    train_case("train_width128_k5_l40", k=5, seed=207, n=12, length=40, batch=6, epochs=1, mid=128)
+
+
 def resnet_variant_cases():
     resnet_variant_case("resnetvar_l192", synth.ukdale_windows(8, 192, seed=21), seeds=[301, 302])
     # shorter than the 7-tap kernel's reach and not a tile multiple: every position touches the zero padding
@@ -437,6 +484,8 @@ def main():
         return metrics_case()
     if len(sys.argv) > 1 and sys.argv[1] == "windows":
         return windows_case()
+    if len(sys.argv) > 1 and sys.argv[1] == "widths":
+        return width_cases()
     if len(sys.argv) > 1 and sys.argv[1] == "cfg0":
         return big_ensemble_case()
     if len(sys.argv) > 1 and sys.argv[1] == "control":
@@ -445,6 +494,7 @@ def main():
         return trainer_valid_case()
     if len(sys.argv) > 1 and sys.argv[1] == "train510":
         return train_case("train_k7_l510", k=7, seed=205, n=128, length=510, batch=128, epochs=1)
+    width_cases()
     big_ensemble_case()
     trainer_control_flow_case()
     trainer_valid_case()

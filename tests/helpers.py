@@ -29,6 +29,13 @@ def case_state_dicts(case):
             for k, g, b in zip(case["members"], case["head_gain"], case["head_bias"])]
 
 
+def width_state_dicts(case):
+    """Members of a ``width*`` fixture: CamALResNet(kernel_size, mid_channels=mid)."""
+    return [weights.make_state_dict(int(k), seed=int(case["seed"]), mid_channels=int(case["mid"]), head_gain=float(g),
+                                    head_bias=tuple(b))
+            for k, g, b in zip(case["members"], case["head_gain"], case["head_bias"])]
+
+
 def resnetvar_state_dicts(case):
     """Members of a ``resnetvar_*`` fixture: classifiers/resnet.py's ResNet (kernels 7/5/3, zero padding)."""
     return [weights.make_state_dict(7, seed=int(sd), arch=weights.ARCH_RESNET, head_gain=float(g), head_bias=tuple(b))
@@ -51,16 +58,18 @@ def train_case_inputs(case):
     k, seed = int(case["k"]), int(case["seed"])
     x, y = synth.ideal_windows(int(case["n"]), int(case["length"]), seed=seed)
     arch = weights.ARCH_RESNET if "resnet_variant" in case and bool(case["resnet_variant"]) else weights.ARCH_CAMAL
-    sd0 = weights.make_state_dict(k, seed=seed, head_gain=1.0, arch=arch)
+    mid = int(case["mid"]) if "mid" in case else 64
+    sd0 = weights.make_state_dict(k, seed=seed, head_gain=1.0, arch=arch, mid_channels=mid)
     return k, x, y, sd0
 
 
 def model_for(sd0):
     """The mirror class a state dict belongs to (CamALResNet, or ResNet for the 7/5/3 zero-padded variant)."""
     from camal_amd.resnet import CamALResNet, ResNet
+    mid = int(np.asarray(sd0["layers.0.layers.0.layers.0.weight"]).shape[0])
     if weights.arch_of(sd0) == weights.ARCH_RESNET:
-        return ResNet()
-    return CamALResNet(kernel_size=weights.kernel_size_of(sd0))
+        return ResNet(mid_channels=mid)
+    return CamALResNet(kernel_size=weights.kernel_size_of(sd0), mid_channels=mid)
 
 
 def is_bn_fed_bias(key):

@@ -247,3 +247,68 @@ def test_resnet_variant_mirror_class(torch_cuda):
     with torch.no_grad():
         ref = FunctionalResNet(resnetvar_state_dicts(c)[0]).forward(torch.from_numpy(c["data"].astype(np.float32))).numpy()
     assert rel_err(lt.T, ref.T) < REL_TOL_FP32
+
+
+# ---- CamALResNet(mid_channels=32 / 128) through camal_create_widths ------------------------------------------------
+@pytest.mark.parametrize("name", golden_cases("width"))
+def test_other_widths_fp32_vs_reference(torch_cuda, name):
+    from camal_amd.engine import Ensemble
+    from tests.helpers import width_state_dicts
+    c = load_case(name)
+    sds = width_state_dicts(c)
+    ens = Ensemble(sds, device="cuda:0", precision="fp32")
+    assert ens.mid_channels == int(c["mid"])
+    logits, cam = ens.forward_cam(c["data"].astype(np.float32))
+    logits, cam = logits.cpu().numpy(), cam.cpu().numpy()
+    for e in range(ens.E):
+        assert rel_err(cam[e], c["cams"][e]) < REL_TOL_FP32
+        assert rel_err(logits[e].T, c["logits"][e].T) < REL_TOL_FP32
+        assert np.abs(_softmax(logits[e]) - c["probs"][e]).max() < REL_TOL_FP32
+    ens.close()
+    with pytest.raises(Exception):  # the bf16 kernels exist for the default widths only
+        Ensemble(sds, device="cuda:0", precision="bf16")
+
+
+@pytest.mark.parametrize("mid,L,k", [(32, 1, 5), (32, 300, 25), (32, 1031, 9), (128, 70, 25), (128, 257, 7), (128, 5, 41)])
+def test_other_widths_localize_vs_oracle(torch_cuda, mid, L, k):
+    """ragged lengths, several tiles per window, the extreme kernel size, the ensemble body on top"""
+    from camal_amd import synth, weights
+    from camal_amd.engine import Ensemble
+    from oracle import camal_oracle as oracle
+    x = synth.ukdale_windows(5, max(L, 8), seed=500 + L)[:, :L].astype(np.float32)
+    sds = [weights.make_state_dict(kk, seed=s, mid_channels=mid, head_gain=3.0) for kk, s in ((k, 321), (7, 322))]
+    ens = Ensemble(sds, device="cuda:0", precision="fp32")
+    res = ens.localize(x, want_avg_cam=True, want_members=True)
+    states, prob, avg_cam, outs = oracle.camal_predict(sds, x, return_intermediate=True)
+    mcam = res["member_cam"].cpu().numpy()
+    for e in range(len(sds)):
+        assert rel_err(mcam[e], outs[e][0]) < REL_TOL_FP32
+    assert np.abs(res["prob"].cpu().numpy() - prob[:, 0]).max() < REL_TOL_FP32
+    safe = np.abs(prob[:, 0] - 0.5) > 2e-3
+    if L >= 5 and safe.any():
+        assert (res["state"].cpu().numpy()[safe] == states[safe]).mean() >= STATE_AGREE_MIN
+    ens.close()
+
+
+def test_other_widths_mirror_class_and_trainer(torch_cuda):
+    """CamALResNet(mid_channels=32) on its own: eval forward, CAM.run, one epoch of the trainer, a 4-D test()-style use"""
+    from camal_amd import CAM, CamALResNet, synth
+    from camal_amd.trainer import BasedClassifTrainer, TSLoader
+    from tests.helpers import width_state_dicts
+    c = load_case("width32_l150")
+    m = CamALResNet(kernel_size=5, mid_channels=32)
+    m.to("cuda:0")
+    m.load_state_dict(width_state_dicts(c)[0])
+    m.eval()
+    lg = m(c["data"].astype(np.float32)[:, None, :]).cpu().numpy()
+    assert rel_err(lg.T, c["logits"][0].T) < REL_TOL_FP32
+    cam = CAM(m, "cuda:0", last_conv_layer=m._modules["layers"][2], fc_layer_name=m._modules["linear"])
+    got, label, proba = cam.run(instance=c["data"][1], returned_cam_for_label=1)
+    assert rel_err(got[None], c["cams"][0][1:2]) < REL_TOL_FP32 and label == int(c["labels"][0][1])
+    x, y = synth.ideal_windows(24, 64, seed=9)
+    m.train()
+    tr = BasedClassifTrainer(m, TSLoader(x, y, batch_size=8, shuffle=True), valid_loader=TSLoader(x[:8], y[:8], batch_size=1),
+                             device="cuda:0", weight_decay=0)
+    tr.train(2)
+    assert len(tr.loss_valid_history) == 2 and np.isfinite(tr.loss_train_history).all()
+    assert m.state_dict()["linear.weight"].shape == (2, 64)

@@ -40,7 +40,7 @@ def test_one_step_vs_reference_fixture(name):
     loss, ncorrect = eng.forward_backward(x[:B], y[:B])
     assert abs(loss.item() - float(c["step1_loss"])) < 1e-4
     grads = _grads_dict(eng, m)
-    keys = weights.trainable_keys(k)
+    keys = eng.keys
     norms, small, big = pack_train_views(keys, grads)
     live = np.array([not is_bn_fed_bias(kk) for kk in keys])
     assert np.allclose(norms[live], c["step1_grad_norms"][live], rtol=1e-3, atol=1e-7)

@@ -67,6 +67,23 @@ def test_resnet_variant_members_match_reference(name):
         assert rel_err(cam0[None], c["cams"][e][:1]) < REL_TOL_FP32 and np.abs(p0 - c["probs"][e][0]).max() < REL_TOL_FP32
 
 
+@pytest.mark.parametrize("name", golden_cases("width"))
+def test_other_widths_match_reference(name):
+    """CamALResNet(mid_channels=32 / 128) (camal_resnet.py:5-19): the oracle against the reference class's own logits
+    and CAM.run rows."""
+    from tests.helpers import width_state_dicts
+    c = load_case(name)
+    for e, sd in enumerate(width_state_dicts(c)):
+        assert sd["linear.weight"].shape == (2, 2 * int(c["mid"]))
+        cams, labels, probs = oracle.cam_batch(sd, c["data"], 1)
+        assert rel_err(cams, c["cams"][e]) < REL_TOL_FP32
+        assert np.abs(probs - c["probs"][e]).max() < REL_TOL_FP32
+        diff = labels != c["labels"][e]
+        assert np.all(np.abs(c["probs"][e][diff, 1] - 0.5) < 1e-4)
+        logits = oracle.resnet_forward(sd, c["data"][:, None, :])
+        assert rel_err(logits.T, c["logits"][e].T) < REL_TOL_FP32
+
+
 def test_resnet_variant_fixtures_present():
     assert len(golden_cases("resnetvar_")) >= 2
 
