@@ -95,6 +95,7 @@ struct Member {
     int k = 0;
     bool loaded = false;
     float *stem_w = nullptr, *stem_b = nullptr, *res1_w = nullptr, *res1_b = nullptr;
+    void* stem_pack = nullptr;  // bf16, default widths: the stem's weights as hi / lo MFMA A fragments (Block1Args::stem_pack)
     Layer conv[8];  // ConvBlocks 1..8 (ConvBlock 0 is the stem)
     Layer res2;
     float* wfc = nullptr;  // [2][128]
@@ -114,6 +115,7 @@ struct camal_ctx {
     int mid = C1;  // mid_channels (camal_resnet.py:8): 64, or 32 / 128 through camal_create_widths (fp32, one kernel per ConvBlock)
     float* zero_row = nullptr;  // 1 KiB of zeros: what a zero-padded layer reads outside the window
     int fused = 1;  // blocks 2 and 3 as fused-block kernels (block_kernel); 0: one conv_kernel per layer
+    int stem_mfma = 1;     // bf16 block1_kernel: the Cin = 1 ConvBlock on MFMA (hi + lo bf16 operands); env CAMAL_STEM_MFMA=0: VALU
     int fused_block1 = 1;  // with fused: block 1 as block1_kernel (env CAMAL_FUSED_BLOCK1=0: stem + two conv_kernels)
     std::vector<Member> m;
     std::vector<void*> owned;  // device allocations freed in destroy
@@ -440,6 +442,7 @@ int launch_block1_w(camal_ctx* c, hipStream_t s, const Member& m, const float* x
     a.w2 = (const uint4*)m.conv[0].wpack; a.w3 = (const uint4*)m.conv[1].wpack;
     a.b2 = m.conv[0].bias; a.b3 = m.conv[1].bias;
     a.L = L; a.ks1 = m.k;
+    a.stem_pack = c->stem_mfma ? (const uint4*)m.stem_pack : nullptr;
     a.tiles_per_window = (L + G::T - 1) / G::T;
     const long long total = (long long)a.tiles_per_window * BC;
     if (total > 0x7fffffffLL) return fail(CAMAL_ERR_ARG, "too many tiles in one pass");
@@ -670,6 +673,7 @@ int camal_create_widths(int device_id, int n_members, const int* kernel_sizes, i
     c->fused = precision == CAMAL_BF16;
     if (const char* e = getenv("CAMAL_FUSED")) c->fused = atoi(e) != 0;
     if (const char* e = getenv("CAMAL_FUSED_BLOCK1")) c->fused_block1 = atoi(e) != 0;
+    if (const char* e = getenv("CAMAL_STEM_MFMA")) c->stem_mfma = atoi(e) != 0;
     if (const char* e = getenv("CAMAL_POST_WINDOWS")) c->post_windows = std::max(1, atoi(e));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
@@ -738,6 +742,27 @@ int camal_set_member_weights(camal_ctx* c, int member, const float* f, size_t n_
                 for (int j = 0; j < ks; ++j) t[(size_t)j * C1 + co] = w[(size_t)co * ks + j];
             if ((r = upload(c, (void**)&m.stem_w, t.data(), t.size() * 4))) return r;
             if ((r = upload(c, (void**)&m.stem_b, b, C1 * 4))) return r;
+            if (c->precision == CAMAL_BF16 && C1 == 64) {
+                // [mt][tap group g][mi][hi | lo][lane][8 x bf16]: w[32 mt + 16 mi + (l & 15)][32 g + 8 (l >> 4) + jj]
+                const int ngrp = (ks + 31) / 32;
+                std::vector<uint16_t> sp((size_t)2 * ngrp * 4 * 64 * 8, 0);
+                for (int mt = 0; mt < 2; ++mt)
+                    for (int g = 0; g < ngrp; ++g)
+                        for (int mi = 0; mi < 2; ++mi)
+                            for (int l = 0; l < 64; ++l)
+                                for (int jj = 0; jj < 8; ++jj) {
+                                    const int co = 32 * mt + 16 * mi + (l & 15), tap = 32 * g + 8 * (l >> 4) + jj;
+                                    const float v = tap < ks ? w[(size_t)co * ks + tap] : 0.f;
+                                    const uint16_t hi = f2bf(v);
+                                    uint32_t hb = (uint32_t)hi << 16;
+                                    float hf;
+                                    memcpy(&hf, &hb, 4);
+                                    const size_t o = ((((size_t)(mt * ngrp + g) * 4 + 2 * mi) * 64 + l) * 8) + jj;
+                                    sp[o] = hi;
+                                    sp[o + 64 * 8] = f2bf(v - hf);
+                                }
+                if ((r = upload(c, &m.stem_pack, sp.data(), sp.size() * 2))) return r;
+            }
         } else if ((r = make_layer(c, m.conv[i - 1], w, b, cout, cin, ks))) return r;
     }
     if ((r = upload(c, (void**)&m.res1_w, p, C1 * 4))) return r;

@@ -1089,6 +1089,10 @@ struct Block1Args {
     const uint4 *w2, *w3;            // packed ConvBlock(7), ConvBlock(3) weights (64 -> 64)
     const float *b2, *b3;
     int L, ks1, tiles_per_window, total_tiles;
+    // bf16: the Cin = 1 ConvBlock's weights as MFMA A fragments, split in two bf16 halves (w = hi + lo):
+    // [channel tile mt][tap group g of 32][mi][hi | lo][lane][16 B]; lane (i = l & 15, q = l >> 4), element jj
+    // <-> w[32 mt + 16 mi + i][tap 32 g + 8 q + jj] (0 past the kernel size).  Null: the VALU stem.
+    const uint4* stem_pack;
 };
 
 template <typename DT, int NT, int NWC = 8>
@@ -1101,8 +1105,11 @@ struct Block1Geom {
     static constexpr int XS = N + 64;               // floats per x buffer (N + k - 1 <= N + 62)
     static constexpr int A1_BYTES = (((N + 6) * RB) + 1023) & ~1023;
     static constexpr int A2_BYTES = (((N + 2) * RB) + 1023) & ~1023;
-    static constexpr int CST_OFF = A1_BYTES + A2_BYTES + 2 * XS * 4;  // LDS copies of b2, b3, wr, br: [4][64] floats
-    static constexpr int LDS_BYTES = CST_OFF + 4 * 64 * 4;
+    static constexpr int CST_OFF = A1_BYTES + A2_BYTES + 2 * XS * 4;  // LDS copies of b2, b3, wr, br, b1: [5][64] floats
+    // bf16 (MFMA stem): the tile's x row once more as bf16 halves, [hi | lo][shift 0..7][XS]: copy s holds the row from
+    // element s on, so that the 8 values from ANY element e on are one 16-byte aligned read of copy e % 8
+    static constexpr int XB_OFF = CST_OFF + 5 * 64 * 4;
+    static constexpr int LDS_BYTES = XB_OFF + (ES == 2 ? 2 * 8 * XS * 2 : 0);
 };
 
 // NWC = 8: one workgroup per CU, 512-column tiles (bf16).  NWC = 4: half the tile, two workgroups per CU.
@@ -1137,12 +1144,35 @@ __global__ __launch_bounds__(NWC * 64) void block1_kernel(Block1Args a, const fl
         cst[64 + i] = a.b3[i];
         cst[128 + i] = res_w[i];
         cst[192 + i] = res_b[i];
+        cst[256 + i] = stem_b[i];
+    }
+    // MFMA stem (bf16): x value i of the tile as bf16 halves into the 8 shifted copies.  The values past the kernel's
+    // last tap meet zero weights and must be finite: the copies start from zeros and only i < nx is ever written.
+    __bf16* xb = reinterpret_cast<__bf16*>(lds + G::XB_OFF);
+    const bool mfma_stem = sizeof(DT) == 2 && a.stem_pack != nullptr;
+    auto put_x = [&](int i, float v) {
+        const __bf16 h = (__bf16)v;
+        const __bf16 l = (__bf16)(v - (float)h);
+#pragma unroll
+        for (int sft = 0; sft < 8; ++sft)
+            if (i - sft >= 0) {
+                xb[sft * G::XS + i - sft] = h;
+                xb[(8 + sft) * G::XS + i - sft] = l;
+            }
+    };
+    if (mfma_stem) {
+        for (int i = threadIdx.x; i < 16 * G::XS / 2; i += TH) reinterpret_cast<unsigned*>(xb)[i] = 0u;
+        __syncthreads();
     }
     constexpr int XPT = (G::XS + TH - 1) / TH;  // x values per thread
     if ((int)blockIdx.x < a.total_tiles)
 #pragma unroll
         for (int u = 0; u < XPT; ++u)
-            if ((int)threadIdx.x + TH * u < nx) xs[threadIdx.x + TH * u] = load_x(blockIdx.x, threadIdx.x + TH * u);
+            if ((int)threadIdx.x + TH * u < nx) {
+                const float v = load_x(blockIdx.x, threadIdx.x + TH * u);
+                xs[threadIdx.x + TH * u] = v;
+                if (mfma_stem) put_x(threadIdx.x + TH * u, v);
+            }
     __syncthreads();
 
     // stem role: channel half sh, 64 columns;  MFMA role: channel tile mt, NT column tiles
@@ -1173,8 +1203,48 @@ __global__ __launch_bounds__(NWC * 64) void block1_kernel(Block1Args a, const fl
         }
 
         STAMP1(0);
-        // ---- ConvBlock(k), 1 -> 64, VALU: a1[c][co] = relu(b[co] + sum_j w[j][co] x[c + j])  -> A1 row c + 3
-        {
+        // ---- ConvBlock(k), 1 -> 64: a1[c][co] = relu(b[co] + sum_j w[j][co] x[c + j])  -> A1 row c + pad2
+        bool stem_done = false;
+        if constexpr (sizeof(DT) == 2) {
+            if (mfma_stem) {
+                // On MFMA (v_mfma_f32_16x16x32_bf16, K = taps in groups of 32): D[co][c] += W[co][j] X[j][c] with
+                // X[j][c] = x[c + j] read straight from the shifted bf16 copies of the x row in LDS (an im2col that is never stored).  x and w are
+                // fp32: each goes in as two bf16 halves (hi = bf16(v), lo = bf16(v - hi)) and three products
+                // (hi hi + lo hi + hi lo) keep 16 bits of each, where the VALU stem this replaces kept 24 — the result is
+                // rounded to bf16 for the next layer either way.  The wave keeps its MFMA role (channel tile mt, columns
+                // colw ..): 4.5 k (k = 7) to 9.4 k (k = 25) cycles of VALU per tile become 48 MFMAs + the operand build.
+                F sacc[NT];
+                init_acc_bias<DT, NT>(sacc, cst + 256, mt, lane);
+                const int ngrp = (ks1 + 31) >> 5;
+                const int bi = F::bcol(lane), bq = lane >> 4;
+                for (int g = 0; g < ngrp; ++g) {
+                    const uint4* sp = a.stem_pack + ((size_t)(mt * ngrp + g) * 4) * 64 + lane;
+                    u32x4 ah[2], al[2];
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) {
+                        ah[mi] = *reinterpret_cast<const u32x4*>(sp + (2 * mi) * 64);
+                        al[mi] = *reinterpret_cast<const u32x4*>(sp + (2 * mi + 1) * 64);
+                    }
+#pragma unroll
+                    for (int f = 0; f < 2 * NT; ++f) {
+                        const int e = colw + 16 * f + bi + 32 * g + 8 * bq;  // first of the lane's 8 x values
+                        const __bf16* xp = xb + (e & 7) * G::XS + (e & ~7);
+                        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(xp);
+                        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(xp + 8 * G::XS);
+#pragma unroll
+                        for (int mi = 0; mi < 2; ++mi) {
+                            f32x4& d = sacc[f >> 1].v[2 * mi + (f & 1)];
+                            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[mi]), bh, d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al[mi]), bh, d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[mi]), bl, d, 0, 0, 0);
+                        }
+                    }
+                }
+                store_act_lds<DT, NT, 64>(A1, colw + pad2, sacc, mt, opaque(lane));
+                stem_done = true;
+            }
+        }
+        if (!stem_done) {  // VALU: wave-uniform weights through scalar loads, one x value per lane, column and tap
             float sacc[SC][32];
 #pragma unroll
             for (int u = 0; u < SC; ++u)
@@ -1277,7 +1347,10 @@ __global__ __launch_bounds__(NWC * 64) void block1_kernel(Block1Args a, const fl
         STAMP1(6);
 #pragma unroll
         for (int u = 0; u < XPT; ++u)
-            if (next < a.total_tiles && (int)threadIdx.x + TH * u < nx) xn[threadIdx.x + TH * u] = xpre[u];
+            if (next < a.total_tiles && (int)threadIdx.x + TH * u < nx) {
+                xn[threadIdx.x + TH * u] = xpre[u];
+                if (mfma_stem) put_x(threadIdx.x + TH * u, xpre[u]);  // the copies were last read by this tile's stem
+            }
         __syncthreads();  // END: A1/A2 free, next x in place
         STAMP1(7);
     }
