@@ -40,6 +40,7 @@ SIGNATURES = {
     "camal_set_fused": (_i, [_vp, _i]),
     "camal_reserve": (_i, [_vp, _i, _i]),
     "camal_forward_cam": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "camal_forward_cam_tap": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "camal_localize": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "camal_postprocess": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _vp, _vp, _vp, _vp, _vp]),
     "camal_attention": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -115,6 +115,8 @@ struct camal_ctx {
     int mid = C1;  // mid_channels (camal_resnet.py:8): 64, or 32 / 128 through camal_create_widths (fp32, one kernel per ConvBlock)
     float* zero_row = nullptr;  // 1 KiB of zeros: what a zero-padded layer reads outside the window
     int fused = 1;  // blocks 2 and 3 as fused-block kernels (block_kernel); 0: one conv_kernel per layer
+    int tap_block = 2;     // camal_forward_cam_tap: 1 = the CAM is taken from block 2's output (into tap_cam)
+    float* tap_cam = nullptr;
     int stem_mfma = 1;     // bf16 block1_kernel: the Cin = 1 ConvBlock on MFMA (hi + lo bf16 operands); env CAMAL_STEM_MFMA=0: VALU
     int fused_block1 = 1;  // with fused: block 1 as block1_kernel (env CAMAL_FUSED_BLOCK1=0: stem + two conv_kernels)
     std::vector<Member> m;
@@ -463,6 +465,19 @@ int launch_block1(camal_ctx* c, hipStream_t s, const Member& m, const float* x, 
     return launch_block1_w<DT, 8>(c, s, m, x, out, BC, L);
 }
 
+// camal_forward_cam_tap with tap_block = 1: the CAM of block 2's output (in `feat`, [BC * L][CH]) into c->tap_cam
+template <typename DT, int CH>
+int launch_cam_tap(camal_ctx* c, hipStream_t s, const Member& m, const void* feat, int BC, int L) {
+    if (c->tap_block != 1 || c->tap_cam == nullptr) return 0;
+    ProfScope ps(c, s, 4);
+    const size_t rows = (size_t)BC * L;
+    const int grid = (int)std::min<size_t>((rows + 255) / 256, 4096);
+    hipLaunchKernelGGL((cam_dot_kernel<DT, CH>), dim3(grid), dim3(256), 0, s, (const DT*)feat, m.wfc + (size_t)c->cam_row * CH,
+                       c->tap_cam, rows);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // One member's conv stack on BC windows, one kernel per ConvBlock, for mid_channels = M (widths 1 -> M -> 2M -> 2M):
 // x -> cam row [BC][L] + pooled partials [BC][ntiles][2].  block1_done: block 1 already ran fused (its output in w.a1)
 template <typename DT, int M>
@@ -486,6 +501,7 @@ int run_member_layers(camal_ctx* c, hipStream_t s, const Member& m, const float*
     if ((r = launch_conv<DT, W1, W2, true, false, false>(c, s, m.conv[2], w.a1, nullptr, w.a2, nullptr, nullptr, nullptr, BC, L))) return r;
     if ((r = launch_conv<DT, W2, W2, true, false, false>(c, s, m.conv[3], w.a2, nullptr, w.b2, nullptr, nullptr, nullptr, BC, L))) return r;
     if ((r = launch_conv<DT, W2, W2, true, true, false>(c, s, m.conv[4], w.b2, w.r2, w.a2, nullptr, nullptr, nullptr, BC, L))) return r;
+    if ((r = launch_cam_tap<DT, W2>(c, s, m, w.a2, BC, L))) return r;
     // block 3: no skip (camal_resnet.py:40-41,59); last ConvBlock fused with the CAM head
     if ((r = launch_conv<DT, W2, W2, true, false, false>(c, s, m.conv[5], w.a2, nullptr, w.b2, nullptr, nullptr, nullptr, BC, L))) return r;
     if ((r = launch_conv<DT, W2, W2, true, false, false>(c, s, m.conv[6], w.b2, nullptr, w.a2, nullptr, nullptr, nullptr, BC, L))) return r;
@@ -517,6 +533,7 @@ int run_member(camal_ctx* c, hipStream_t s, const Member& m, const float* x, int
         }
         // blocks 2 and 3: one fused kernel each (three ConvBlocks through LDS)
         if ((r = launch_block<DT, C1, true, false>(c, s, m.conv[2], m.conv[3], m.conv[4], &m.res2, w.a1, w.a2, nullptr, nullptr, nullptr, BC, L))) return r;
+        if ((r = launch_cam_tap<DT, C2>(c, s, m, w.a2, BC, L))) return r;
         if ((r = launch_block<DT, C2, false, true>(c, s, m.conv[5], m.conv[6], m.conv[7], nullptr, w.a2, nullptr, m.wfc, cam, part, BC, L, cmax))) return r;
         return 0;
     }
@@ -780,7 +797,13 @@ int camal_set_member_weights(camal_ctx* c, int member, const float* f, size_t n_
 
 int camal_forward_cam(camal_ctx* c, const float* x, int B, int L, int member, int cam_label, float* logits, float* cam,
                       void* stream) {
+    return camal_forward_cam_tap(c, x, B, L, member, cam_label, 2, logits, cam, stream);
+}
+
+int camal_forward_cam_tap(camal_ctx* c, const float* x, int B, int L, int member, int cam_label, int tap_block,
+                          float* logits, float* cam, void* stream) {
     if (int r = check_ctx(c, B, L)) return r;
+    if (tap_block != 1 && tap_block != 2) return fail(CAMAL_ERR_ARG, "tap_block must be 1 (second ResNetBlock) or 2 (last ResNetBlock)");
     if (cam_label != 0 && cam_label != 1) return fail(CAMAL_ERR_ARG, "cam_label must be 0 or 1");
     c->cam_row = cam_label;
     if (!x || !logits) return fail(CAMAL_ERR_ARG, "x_dev and logits_dev are required");
@@ -794,7 +817,13 @@ int camal_forward_cam(camal_ctx* c, const float* x, int B, int L, int member, in
         const int n = std::min(BC, B - c0);
         for (int e = e0; e < e1; ++e) {
             float* camw = w.cam;  // member rows are consumed immediately: one row buffer is enough
-            if (int r = run_member_any(c, s, c->m[e], x + (size_t)c0 * L, n, L, w, camw, w.part, w.logits, nullptr)) return r;
+            // tap_block 1: the hooked layer is block 2; its CAM goes to r1 (block 1's skip, free once block 1 is done)
+            c->tap_block = (tap_block == 1 && cam) ? 1 : 2;
+            c->tap_cam = c->tap_block == 1 ? (float*)w.r1 : nullptr;
+            const int rr = run_member_any(c, s, c->m[e], x + (size_t)c0 * L, n, L, w, camw, w.part, w.logits, nullptr);
+            if (c->tap_block == 1) camw = c->tap_cam;
+            c->tap_block = 2; c->tap_cam = nullptr;
+            if (rr) return rr;
             HIP_TRY(hipMemcpyAsync(logits + ((size_t)(e - e0) * B + c0) * 2, w.logits, (size_t)n * 2 * 4, hipMemcpyDeviceToDevice, s));
             if (cam) HIP_TRY(hipMemcpyAsync(cam + ((size_t)(e - e0) * B + c0) * L, camw, (size_t)n * L * 4, hipMemcpyDeviceToDevice, s));
         }

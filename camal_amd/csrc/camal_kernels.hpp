@@ -1356,6 +1356,29 @@ __global__ __launch_bounds__(NWC * 64) void block1_kernel(Block1Args a, const fl
     }
 }
 
+// CAM of a hooked layer other than the last block (class_activation_map.py:25-31,42-48 with last_conv_layer =
+// layers[1]): cam[r] = sum_c W_fc[label][c] * F[r][c] over the C channels of block 2's output F [rows][C]
+// (channels-last, DT).  One row per lane, 16-byte chunks; HBM-bound, off the hot path.
+template <typename DT, int C>
+__global__ __launch_bounds__(256) void cam_dot_kernel(const DT* __restrict__ feat, const float* __restrict__ wrow,
+                                                      float* __restrict__ cam, size_t rows) {
+    __shared__ float w[C];
+    for (int i = threadIdx.x; i < C; i += 256) w[i] = wrow[i];
+    __syncthreads();
+    for (size_t r = (size_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (size_t)gridDim.x * 256) {
+        const DT* f = feat + r * C;
+        float acc = 0.f;
+#pragma unroll 4
+        for (int c = 0; c < C; c += 4) {
+            float v[4];
+            load4(f + c, v);
+            acc = fmaf(w[c], v[0], acc); acc = fmaf(w[c + 1], v[1], acc);
+            acc = fmaf(w[c + 2], v[2], acc); acc = fmaf(w[c + 3], v[3], acc);
+        }
+        cam[r] = acc;
+    }
+}
+
 // logits[b][k] = (sum over tiles of part[b][tile][k]) / L + b_fc[k]   (camal_resnet.py:23)
 __device__ __forceinline__ void member_logits(const float* part, int ntiles, int L, const float* bfc, float& l0,
                                               float& l1) {

@@ -133,16 +133,17 @@ class Ensemble:
         return x.to(device=self.device, dtype=torch.float32).contiguous()
 
     # --- CamALResNet.forward + CAM.run for a batch (camal_forward_cam) -------------------
-    def forward_cam(self, x, member=-1, want_cam=True, cam_label=1):
-        """-> (logits [E,B,2] float32, cam [E,B,L] float32 or None) as device tensors."""
+    def forward_cam(self, x, member=-1, want_cam=True, cam_label=1, tap_block=2):
+        """-> (logits [E,B,2] float32, cam [E,B,L] float32 or None) as device tensors.  tap_block: the ResNetBlock the
+        CAM is taken from (2 = the last one; 1 = the second, ``CAM(last_conv_layer=layers[1])``)."""
         x = self._as_x(x)
         B, L = x.shape
         eo = self.E if member < 0 else 1
         with torch.cuda.device(self.device):
             logits = torch.empty((eo, B, 2), dtype=torch.float32, device=self.device)
             cam = torch.empty((eo, B, L), dtype=torch.float32, device=self.device) if want_cam else None
-            _lib.check(self.lib.camal_forward_cam(self._h, _lib.ptr(x), B, L, member, cam_label,
-                                                  _lib.ptr(logits), _lib.ptr(cam), self._stream()))
+            _lib.check(self.lib.camal_forward_cam_tap(self._h, _lib.ptr(x), B, L, member, cam_label, int(tap_block),
+                                                      _lib.ptr(logits), _lib.ptr(cam), self._stream()))
         return logits, cam
 
     # --- CamAL.predict body + power step (camal_localize) ---------------------------------

@@ -106,6 +106,14 @@ int camal_set_fused(camal_ctx* ctx, int fused);
 int camal_forward_cam(camal_ctx* ctx, const float* x_dev, int B, int L, int member, int cam_label,
                       float* logits_dev, float* cam_dev, void* stream);
 
+/* camal_forward_cam with the hook on another layer (CAM's last_conv_layer argument, class_activation_map.py:25-31):
+ * tap_block 2 = the last ResNetBlock (camal_forward_cam, what CamAL.eval passes, core.py:403); 1 = the second
+ * ResNetBlock, whose output has the width the head's weights have: cam[t] = sum_c W_fc[cam_label][c] * F2[c][t].
+ * The logits are the model's either way.  (The first block's output is narrower than W_fc: the reference's dot
+ * product fails on it.)                                                                                           */
+int camal_forward_cam_tap(camal_ctx* ctx, const float* x_dev, int B, int L, int member, int cam_label, int tap_block,
+                          float* logits_dev, float* cam_dev, void* stream);
+
 /* Fused detection + localization + power.  Replaces the body of CamAL.predict
  * (core.py:286-327: member loop, softmax, clip/normalise/average, vote gate,
  * attention_sigmoid_module :415-437) and CamAL.test's power step (core.py:216-218).

@@ -469,6 +469,36 @@ def width_cases():
     train_case("train_width128_k5_l40", k=5, seed=207, n=12, length=40, batch=6, epochs=1, mid=128)
 
 
+def camtap_case(name="camtap_l120", k=9, seed=403, mid=64):
+    """CAM with the hook on another layer (class_activation_map.py:25-31): last_conv_layer = the SECOND ResNetBlock of
+    the reference model; rows for label 1 and for the predicted label (returned_cam_for_label=None, label_instance=0)."""
+    data = synth.ukdale_windows(6, 120, seed=25)
+    m = CamALResNet(kernel_size=k, mid_channels=mid)
+    m.load_state_dict(to_torch_sd(weights.make_state_dict(k, seed=seed, mid_channels=mid)))
+    m.eval()
+    with torch.no_grad():
+        lg = m(torch.from_numpy(data[:, None, :]).float()).numpy()
+    d = (lg[:, 1] - lg[:, 0]).astype(np.float64)
+    gain = float(np.float32(2.0 / max(d.std(), 1e-6)))
+    bias = (0.0, float(np.float32(-gain * np.median(d))))
+    sd = weights.make_state_dict(k, seed=seed, mid_channels=mid, head_gain=gain, head_bias=bias)
+    m.load_state_dict(to_torch_sd(sd))
+    cam = CAM(model=m, device="cpu", last_conv_layer=m._modules["layers"][1], fc_layer_name=m._modules["linear"])
+    n, length = data.shape
+    cams1 = np.zeros((n, length), np.float32)
+    camsp = np.zeros((n, length), np.float32)
+    labels = np.zeros(n, np.int32)
+    probs = np.zeros((n, 2), np.float32)
+    for i in range(n):
+        c, lab, p = cam.run(instance=data[i], returned_cam_for_label=1)
+        cams1[i], labels[i], probs[i] = c, lab, p
+        c2, _, _ = cam.run(instance=data[i], label_instance=0)
+        camsp[i] = c2
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), k=np.array(k), seed=np.array(seed), mid=np.array(mid), data=data,
+                        head_gain=np.array(gain), head_bias=np.array(bias), cams_label1=cams1, cams_predicted=camsp, labels=labels, probs=probs)
+    print(f"{name}: labels={labels.tolist()} p1={probs[:, 1].round(3).tolist()}")
+
+
 def resnet_variant_cases():
     resnet_variant_case("resnetvar_l192", synth.ukdale_windows(8, 192, seed=21), seeds=[301, 302])
     # shorter than the 7-tap kernel's reach and not a tile multiple: every position touches the zero padding
@@ -484,6 +514,8 @@ def main():
         return metrics_case()
     if len(sys.argv) > 1 and sys.argv[1] == "windows":
         return windows_case()
+    if len(sys.argv) > 1 and sys.argv[1] == "camtap":
+        return camtap_case()
     if len(sys.argv) > 1 and sys.argv[1] == "widths":
         return width_cases()
     if len(sys.argv) > 1 and sys.argv[1] == "cfg0":
@@ -495,6 +527,7 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "train510":
         return train_case("train_k7_l510", k=7, seed=205, n=128, length=510, batch=128, epochs=1)
     width_cases()
+    camtap_case()
     big_ensemble_case()
     trainer_control_flow_case()
     trainer_valid_case()

@@ -186,3 +186,39 @@ def test_streaming_predict_equals_one_shot(dtype):
     r1 = ens.localize(x[:5].astype(np.float32), x64=x[:5] if is64 else None, pred_f64=is64)
     assert np.array_equal(s1, r1["state"].cpu().numpy().astype(np.float64))
     ens.close()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_cam_hook_on_the_second_block(precision):
+    """CAM(last_conv_layer = model.layers[1]) (class_activation_map.py:25-31): tests/golden/camtap_l120.npz holds the
+    reference's rows for label 1 and for the predicted label; the first block is refused (its 64 channels do not match
+    the head's 128 weights: the reference's dot product fails there too)."""
+    from camal_amd import CAM, CamALResNet, weights
+    from camal_amd.engine import Ensemble
+    c = load_case("camtap_l120")
+    sd = weights.make_state_dict(int(c["k"]), seed=int(c["seed"]), mid_channels=int(c["mid"]), head_gain=float(c["head_gain"]),
+                                 head_bias=tuple(c["head_bias"]))
+    assert 0 < c["labels"].sum() < len(c["labels"])  # both classes are predicted: the label-0 rows are exercised
+    if precision == "fp32":
+        m = CamALResNet(kernel_size=int(c["k"]))
+        m.to("cuda:0")
+        m.load_state_dict(sd)
+        m.eval()
+        cam = CAM(m, "cuda:0", last_conv_layer=m._modules["layers"][1], fc_layer_name=m._modules["linear"])
+        rows1, labels, probs = cam.run_batch(c["data"], 1)
+        assert rel_err(rows1, c["cams_label1"]) < REL_TOL_FP32
+        assert np.abs(probs - c["probs"]).max() < REL_TOL_FP32 and np.array_equal(labels, c["labels"])
+        rowsp, _, _ = cam.run_batch(c["data"], None)
+        assert rel_err(rowsp, c["cams_predicted"]) < REL_TOL_FP32
+        one, lab, _ = cam.run(instance=c["data"][2], returned_cam_for_label=1)
+        assert rel_err(one[None], c["cams_label1"][2:3]) < REL_TOL_FP32 and lab == int(c["labels"][2])
+        with pytest.raises(ValueError):
+            CAM(m, "cuda:0", last_conv_layer=m._modules["layers"][0], fc_layer_name=m._modules["linear"])
+        # the last block through the same entry point is what it always was
+        last = CAM(m, "cuda:0", last_conv_layer=m._modules["layers"][2], fc_layer_name=m._modules["linear"])
+        assert last.tap_block == 2
+    else:
+        ens = Ensemble([sd], device="cuda:0", precision="bf16")  # fused blocks: the tap sits between block 2 and block 3
+        _, cam = ens.forward_cam(c["data"], cam_label=1, tap_block=1)
+        assert rel_err(cam[0].cpu().numpy(), c["cams_label1"]) < 3e-2
+        ens.close()
