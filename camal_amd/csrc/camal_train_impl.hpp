@@ -94,7 +94,8 @@ inline int gs_blocks(size_t n, int cap = 4096) { return (int)std::min<size_t>((n
 
 int wgrad_splits(const camal_trainer* t, const TLayer& l, int B, int* wps_out) {
     const int tiles = (l.cin / 32) * ((l.ks + WG_TAPS - 1) / WG_TAPS);
-    int want = std::max(1, (3 * t->num_cu) / std::max(1, tiles));
+    static const int per_cu = getenv("CAMAL_WGRAD_PER_CU") ? std::max(1, atoi(getenv("CAMAL_WGRAD_PER_CU"))) : 3;
+    int want = std::max(1, (per_cu * t->num_cu) / std::max(1, tiles));
     want = std::min(want, B);
     const int wps = (B + want - 1) / want;
     *wps_out = wps;
