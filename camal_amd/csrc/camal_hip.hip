@@ -89,6 +89,7 @@ struct Layer {
     int cin = 0, cout = 0, ks = 0;
     void* wpack = nullptr;   // [MT][ks][NCP][64][16 B]
     float* bias = nullptr;   // [cout]
+    std::vector<char> host_pack;  // bf16, default widths: kept until the member's block streams are built
 };
 
 struct Member {
@@ -98,6 +99,8 @@ struct Member {
     void* stem_pack = nullptr;  // bf16, default widths: the stem's weights as hi / lo MFMA A fragments (Block1Args::stem_pack)
     Layer conv[8];  // ConvBlocks 1..8 (ConvBlock 0 is the stem)
     Layer res2;
+    void *stream2 = nullptr, *stream3 = nullptr;  // bf16 fused blocks 2 / 3: A fragments of all layers, one stream per out-channel tile
+    int stride2 = 0, stride3 = 0;                 // bytes between the streams of consecutive out-channel tiles
     float* wfc = nullptr;  // [2][128]
     float* bfc = nullptr;  // [2]
 };
@@ -191,9 +194,40 @@ std::vector<char> pack_weights(const float* w, int cout, int cin, int ks, int pr
 int make_layer(camal_ctx* c, Layer& ly, const float* w, const float* b, int cout, int cin, int ks) {
     ly.cin = cin; ly.cout = cout; ly.ks = ks;
     std::vector<char> p = pack_weights(w, cout, cin, ks, c->precision);
-    p.resize(p.size() + 8192, 0);  // the bf16 weight ring runs 3 groups (6 KiB) past the last out-channel tile's end
+    const size_t packed = p.size();
+    p.resize(packed + 8192, 0);  // the bf16 weight ring runs 3 groups (6 KiB) past the last out-channel tile's end
     if (int r = upload(c, &ly.wpack, p.data(), p.size())) return r;
+    if (c->precision == CAMAL_BF16 && cout == 128) {
+        p.resize(packed);
+        ly.host_pack.swap(p);
+    }
     return upload(c, (void**)&ly.bias, b, cout * sizeof(float));
+}
+
+// bf16 fused block: per out-channel tile mt (4 of them) the packed A fragments of the block's layers back to back,
+// then the first 3 groups (2 KiB each) of the first layer again: what block_kernel's weight ring (WRing) walks
+// without ever restarting.  Frees the layers' host copies.
+int make_block_stream(camal_ctx* c, std::vector<Layer*> ls, void** out, int* stride) {
+    size_t per_mt = 3 * 2048;
+    for (Layer* l : ls) {
+        if (l->cout != 128 || l->host_pack.size() != (size_t)4 * l->ks * (l->cin / 32) * 2048)
+            return fail(CAMAL_ERR_STATE, "block stream: unexpected layer shape");
+        per_mt += l->host_pack.size() / 4;
+    }
+    std::vector<char> s(4 * per_mt);
+    for (int mt = 0; mt < 4; ++mt) {
+        char* d = s.data() + mt * per_mt;
+        for (Layer* l : ls) {
+            const size_t chunk = l->host_pack.size() / 4;
+            memcpy(d, l->host_pack.data() + mt * chunk, chunk);
+            d += chunk;
+        }
+        memcpy(d, ls[0]->host_pack.data() + mt * (ls[0]->host_pack.size() / 4), 3 * 2048);
+    }
+    *stride = (int)per_mt;
+    if (int r = upload(c, out, s.data(), s.size())) return r;
+    for (Layer* l : ls) std::vector<char>().swap(l->host_pack);
+    return 0;
 }
 
 // ---- workspace ------------------------------------------------------------------------
@@ -206,9 +240,12 @@ struct Workspace {
 
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
+#ifndef CAMAL_BF16_BLOCK_WAVES
+#define CAMAL_BF16_BLOCK_WAVES 4
+#endif
 template <typename DT> struct BlockNT;
-template <> struct BlockNT<float> { static constexpr int NT = 2; };
-template <> struct BlockNT<__bf16> { static constexpr int NT = 4; };
+template <> struct BlockNT<float> { static constexpr int NT = 2; static constexpr int NWC = 8; };
+template <> struct BlockNT<__bf16> { static constexpr int NWC = CAMAL_BF16_BLOCK_WAVES; static constexpr int NT = 32 / NWC; };
 
 // wave = 32 out-channels x NT column tiles; NWC = 8: two column groups
 template <typename DT, int CIN, int NWC>
@@ -227,7 +264,7 @@ size_t block_lds(int k) {
 // other's MFMAs: measured again on the 16x16x32 kernels, 10 % slower.)
 template <typename DT, int CIN, bool HAS_RES, bool HEAD>
 int block_nwc(size_t lds_per_cu, int k) {
-    return block_lds<DT, CIN, 8, HAS_RES, HEAD>(k) > lds_per_cu ? 0 : 8;
+    return block_lds<DT, CIN, BlockNT<DT>::NWC, HAS_RES, HEAD>(k) > lds_per_cu ? 0 : BlockNT<DT>::NWC;
 }
 
 // can this member's blocks 2/3 run fused (LDS budget depends on the first kernel size)?
@@ -240,7 +277,7 @@ bool fused_fits(const camal_ctx* c, int k) {
 
 template <typename DT>
 int fused_head_tile(size_t lds_per_cu, int k) {
-    return BGeom<DT, C2, 8>::T;
+    return BGeom<DT, C2, BlockNT<DT>::NWC>::T;
 }
 
 // the per-layer CAM head is the k = 3 ConvBlock on CH = 2 mid channels: its tile configuration follows use_small_wg
@@ -391,7 +428,7 @@ int launch_conv(camal_ctx* c, hipStream_t s, const Layer& ly, const void* in, co
 // VARIANT: classifiers/resnet.py's block (second kernel 5, zero padding) instead of CamALResNet's (7, replicate)
 template <typename DT, int CIN, int NWC, bool HAS_RES, bool HEAD, bool VARIANT = false>
 int launch_block_w(camal_ctx* c, hipStream_t s, const Layer& l1, const Layer& l2, const Layer& l3, const Layer* lr,
-                   const void* in, void* out, const float* wfc, float* cam, float* part, int BC, int L, float* cmax) {
+                   const void* wstream, int wstride, const void* in, void* out, const float* wfc, float* cam, float* part, int BC, int L, float* cmax) {
     constexpr int NTB = BlockNT<DT>::NT;
     using G = BGeom<DT, CIN, NWC>;
     auto kern = block_kernel<DT, CIN, NTB, NWC, 1, HAS_RES, HEAD, VARIANT ? 5 : 7, VARIANT>;
@@ -406,6 +443,8 @@ int launch_block_w(camal_ctx* c, hipStream_t s, const Layer& l1, const Layer& l2
     a.wfc = wfc; a.cam = cam; a.part = part; a.cmax = cmax;
     a.L = L; a.ks1 = l1.ks; a.cam_row = c->cam_row;
     a.zero_row = c->zero_row;
+    a.wstream = (const char*)wstream; a.wstride = wstride;
+    if (sizeof(DT) == 2 && (wstream == nullptr || (l1.ks & 1) == 0)) return fail(CAMAL_ERR_STATE, "fused block: no weight stream (odd first kernel sizes only)");
     if (l2.ks != (VARIANT ? 5 : 7) || l3.ks != 3) return fail(CAMAL_ERR_STATE, "fused block: unexpected layer kernel sizes");
     a.tiles_per_window = (L + G::T - 1) / G::T;
     const long long total = (long long)a.tiles_per_window * BC;
@@ -421,12 +460,13 @@ int launch_block_w(camal_ctx* c, hipStream_t s, const Layer& l1, const Layer& l2
 
 template <typename DT, int CIN, bool HAS_RES, bool HEAD>
 int launch_block(camal_ctx* c, hipStream_t s, const Layer& l1, const Layer& l2, const Layer& l3, const Layer* lr,
-                 const void* in, void* out, const float* wfc, float* cam, float* part, int BC, int L,
+                 const void* wstream, int wstride, const void* in, void* out, const float* wfc, float* cam, float* part, int BC, int L,
                  float* cmax = nullptr) {
     const int nwc = block_nwc<DT, CIN, HAS_RES, HEAD>(c->lds_per_cu, l1.ks);
-    if (nwc == 8 && c->arch == CAMAL_ARCH_RESNET)
-        return launch_block_w<DT, CIN, 8, HAS_RES, HEAD, true>(c, s, l1, l2, l3, lr, in, out, wfc, cam, part, BC, L, cmax);
-    if (nwc == 8) return launch_block_w<DT, CIN, 8, HAS_RES, HEAD>(c, s, l1, l2, l3, lr, in, out, wfc, cam, part, BC, L, cmax);
+    constexpr int NWC = BlockNT<DT>::NWC;
+    if (nwc == NWC && c->arch == CAMAL_ARCH_RESNET)
+        return launch_block_w<DT, CIN, NWC, HAS_RES, HEAD, true>(c, s, l1, l2, l3, lr, wstream, wstride, in, out, wfc, cam, part, BC, L, cmax);
+    if (nwc == NWC) return launch_block_w<DT, CIN, NWC, HAS_RES, HEAD>(c, s, l1, l2, l3, lr, wstream, wstride, in, out, wfc, cam, part, BC, L, cmax);
     return fail(CAMAL_ERR_ARG, "kernel size too large for the fused block tile");
 }
 
@@ -532,9 +572,9 @@ int run_member(camal_ctx* c, hipStream_t s, const Member& m, const float* x, int
             if ((r = launch_conv<DT, C1, C1, true, true, false>(c, s, m.conv[1], w.b1, w.r1, w.a1, nullptr, nullptr, nullptr, BC, L))) return r;
         }
         // blocks 2 and 3: one fused kernel each (three ConvBlocks through LDS)
-        if ((r = launch_block<DT, C1, true, false>(c, s, m.conv[2], m.conv[3], m.conv[4], &m.res2, w.a1, w.a2, nullptr, nullptr, nullptr, BC, L))) return r;
+        if ((r = launch_block<DT, C1, true, false>(c, s, m.conv[2], m.conv[3], m.conv[4], &m.res2, m.stream2, m.stride2, w.a1, w.a2, nullptr, nullptr, nullptr, BC, L))) return r;
         if ((r = launch_cam_tap<DT, C2>(c, s, m, w.a2, BC, L))) return r;
-        if ((r = launch_block<DT, C2, false, true>(c, s, m.conv[5], m.conv[6], m.conv[7], nullptr, w.a2, nullptr, m.wfc, cam, part, BC, L, cmax))) return r;
+        if ((r = launch_block<DT, C2, false, true>(c, s, m.conv[5], m.conv[6], m.conv[7], nullptr, m.stream3, m.stride3, w.a2, nullptr, m.wfc, cam, part, BC, L, cmax))) return r;
         return 0;
     }
     return run_member_layers<DT, C1>(c, s, m, x, BC, L, w, cam, part, cmax, false);
@@ -788,6 +828,10 @@ int camal_set_member_weights(camal_ctx* c, int member, const float* f, size_t n_
     p += C1;
     if ((r = make_layer(c, m.res2, p, p + (size_t)C2 * C1, C2, C1, 1))) return r;
     p += (size_t)C2 * C1 + C2;
+    if (c->precision == CAMAL_BF16 && c->mid == 64) {
+        if ((r = make_block_stream(c, {&m.conv[2], &m.conv[3], &m.conv[4], &m.res2}, &m.stream2, &m.stride2))) return r;
+        if ((r = make_block_stream(c, {&m.conv[5], &m.conv[6], &m.conv[7]}, &m.stream3, &m.stride3))) return r;
+    }
     if ((r = upload(c, (void**)&m.wfc, p, 2 * C2 * 4))) return r;
     p += 2 * C2;
     if ((r = upload(c, (void**)&m.bfc, p, 2 * 4))) return r;

@@ -100,9 +100,19 @@ template <> struct Frag<__bf16> {
 __device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
     *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
 }
+// two floats -> one dword of two bf16 (round to nearest even) in ONE v_cvt_pk_bf16_f32: hipcc turns a 4-vector
+// conversion into four single-value converts and two v_perm_b32 (3x the instructions; the bf16 epilogues are
+// VALU-issue bound), a 2-vector conversion into the packed instruction
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
 __device__ __forceinline__ void store4(__bf16* p, float a, float b, float c, float d) {
-    bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
-    *reinterpret_cast<bf16x4*>(p) = v;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 v = {pk_bf16(a, b), pk_bf16(c, d)};
+    *reinterpret_cast<u32x2*>(p) = v;
 }
 __device__ __forceinline__ void load4(const float* p, float (&v)[4]) {
     float4 t = *reinterpret_cast<const float4*>(p);
@@ -323,23 +333,25 @@ template <int N> __device__ __forceinline__ void w_wait2(u32x4& r0, u32x4& r1) {
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(N) : "memory");
 }
 
-// group in ring slot S: issue the loads of the group 3 ahead, wait for this group's fragments, 2 MFMAs per B
-// fragment, each followed by the read of the next group's fragment (at LDS address bnext) into the same registers
-template <int RB, int NT, int S>
+// group in ring slot S (mod 4): issue the loads of the group 3 ahead, wait for this group's fragments, 2 MFMAs per B
+// fragment, each followed by the read of the next group's fragment (at LDS address bnext) into the same registers.
+// FIRST: the layer's first group: the accumulators START as mfma(a, b, bias fragment of the lane's 4 channels), so
+// a layer costs no accumulator initialisation (128 v_mov per wave and layer at NT = 8 otherwise).
+template <int RB, int NT, int S, bool FIRST = false>
 __device__ __forceinline__ void bf16_group(const char*& wptr, unsigned loff, unsigned bnext, u32x4 (&a)[4][2],
-                                           u32x4 (&b)[2 * NT], Frag<__bf16> (&acc)[NT]) {
-    constexpr int NF = 2 * NT;
-    w_load2(a[(S + 3) % 4][0], a[(S + 3) % 4][1], wptr, loff);
+                                           u32x4 (&b)[2 * NT], Frag<__bf16> (&acc)[NT], const f32x4* bias = nullptr) {
+    constexpr int NF = 2 * NT, SL = S % 4;
+    w_load2(a[(SL + 3) % 4][0], a[(SL + 3) % 4][1], wptr, loff);
     wptr += 2048;
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
         __builtin_amdgcn_sched_barrier(0);
-        if (f == 0) w_wait2<6>(a[S][0], a[S][1]);  // all but the 3 younger groups' loads have landed
+        if (f == 0) w_wait2<6>(a[SL][0], a[SL][1]);  // all but the 3 younger groups' loads have landed
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
             acc[f >> 1].v[2 * mi + (f & 1)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                *reinterpret_cast<const bf16x8*>(&a[S][mi]), *reinterpret_cast<const bf16x8*>(&b[f]),
-                acc[f >> 1].v[2 * mi + (f & 1)], 0, 0, 0);
+                *reinterpret_cast<const bf16x8*>(&a[SL][mi]), *reinterpret_cast<const bf16x8*>(&b[f]),
+                FIRST ? bias[mi] : acc[f >> 1].v[2 * mi + (f & 1)], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         b[f] = lds_read16(bnext + f * 16 * RB);
     }
@@ -352,11 +364,11 @@ __device__ __forceinline__ unsigned b_addr(unsigned base, int row, int q) {
 }
 
 // the NG groups of one tap, first ring slot S0: cur / nxt = b_addr of this tap / of the tap that follows
-template <int CIN, int NT, int S0>
+template <int CIN, int NT, int S0, bool FIRST = false>
 __device__ __forceinline__ void bf16_tap(const char*& wptr, unsigned loff, unsigned cur, unsigned nxt, u32x4 (&a)[4][2],
-                                         u32x4 (&b)[2 * NT], Frag<__bf16> (&acc)[NT]) {
+                                         u32x4 (&b)[2 * NT], Frag<__bf16> (&acc)[NT], const f32x4* bias = nullptr) {
     constexpr int RB = CIN * 2, NG = CIN / 32;
-    bf16_group<RB, NT, S0>(wptr, loff, cur ^ (1u << 6), a, b, acc);
+    bf16_group<RB, NT, S0, FIRST>(wptr, loff, cur ^ (1u << 6), a, b, acc, bias);
     if constexpr (NG == 2) {
         bf16_group<RB, NT, S0 + 1>(wptr, loff, nxt, a, b, acc);
     } else {
@@ -411,6 +423,87 @@ __device__ __forceinline__ void mma_layer_bf16(const char* buf, int Rb, int ks, 
     // the ring's last loads (past the layer's end) are still in flight: nothing may reuse their registers before they land
 #pragma unroll
     for (int d = 0; d < 4; ++d) w_wait2<0>(a[d][0], a[d][1]);
+}
+
+// The weight ring of the fused blocks never stops: the host lays the A fragments of ALL the layers of a block out
+// as one stream per out-channel tile, [layer 1 | layer 2 | layer 3 | 1x1 skip | first 3 groups of layer 1 again]
+// (camal_hip.hip: make_block_stream), so the 3 groups the ring holds in flight at the end of a layer ARE the next
+// layer's first groups (after the last layer: the next tile's) and no layer starts by waiting an L2 round trip.
+// The ring slot of a layer's first group is then static per layer (PH): 0 where every layer has 4 groups per tap;
+// with 64 input channels (2 groups per tap, odd first kernel) layer 1 ends on slot 2.
+struct WRing {
+    u32x4 a[4][2];
+    const char* wptr;  // next group to load (wave-uniform)
+};
+__device__ __forceinline__ void ring_begin(WRing& r, const char* base, unsigned loff) {
+    r.wptr = base;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        w_load2(r.a[d][0], r.a[d][1], r.wptr, loff);
+        r.wptr += 2048;
+    }
+}
+__device__ __forceinline__ void ring_drain(WRing& r) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) w_wait2<0>(r.a[d][0], r.a[d][1]);
+}
+
+// One layer off the running ring.  BIAS: the accumulators start from the layer's bias (bias_lds = the LDS copy of
+// the wave's 32 bias values), through the C operand of the first group's MFMAs; else the products add to acc.
+template <int CIN, int NT, int PH, bool BIAS>
+__device__ __forceinline__ void mma_stream_bf16(const char* buf, int Rb, int ks, WRing& r, Frag<__bf16> (&acc)[NT],
+                                                const float* bias_lds) {
+    constexpr int RB = CIN * 2, NG = CIN / 32;
+    static_assert(NG == 2 || NG == 4, "64 or 128 input channels");
+    constexpr int NF = 2 * NT;
+    const int lane = threadIdx.x & 63;
+    const unsigned loff = lane * 16;
+    const int q = Frag<__bf16>::kblock(lane);
+    const int R0 = Rb + Frag<__bf16>::bcol(lane);
+    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)buf;
+    f32x4 bias[2];
+    if constexpr (BIAS) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) bias[mi] = *reinterpret_cast<const f32x4*>(bias_lds + 16 * mi + 4 * (lane >> 4));
+    }
+    u32x4 b[NF];
+    unsigned cur = b_addr<RB>(base, R0, q);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) b[f] = lds_read16(cur + f * 16 * RB);
+    if constexpr (NG == 4) {
+        int j = 0;
+        if constexpr (BIAS) {
+            const unsigned nxt = 1 < ks ? b_addr<RB>(base, R0 + 1, q) : cur;
+            bf16_tap<CIN, NT, PH, true>(r.wptr, loff, cur, nxt, r.a, b, acc, bias);
+            cur = nxt;
+            j = 1;
+        }
+#pragma unroll 1
+        for (; j < ks; ++j) {
+            const unsigned nxt = j + 1 < ks ? b_addr<RB>(base, R0 + j + 1, q) : cur;  // past the end: any valid address
+            bf16_tap<CIN, NT, PH>(r.wptr, loff, cur, nxt, r.a, b, acc);
+            cur = nxt;
+        }
+    } else {
+        int j = 0;
+        if constexpr (BIAS) {  // ks >= 2
+            const unsigned mid = b_addr<RB>(base, R0 + 1, q);
+            const unsigned nxt = 2 < ks ? b_addr<RB>(base, R0 + 2, q) : mid;
+            bf16_tap<CIN, NT, PH, true>(r.wptr, loff, cur, mid, r.a, b, acc, bias);
+            bf16_tap<CIN, NT, PH + 2>(r.wptr, loff, mid, nxt, r.a, b, acc);
+            cur = nxt;
+            j = 2;
+        }
+#pragma unroll 1
+        for (; j + 2 <= ks; j += 2) {  // two taps = 4 groups per body: static ring slots
+            const unsigned mid = b_addr<RB>(base, R0 + j + 1, q);
+            const unsigned nxt = j + 2 < ks ? b_addr<RB>(base, R0 + j + 2, q) : mid;
+            bf16_tap<CIN, NT, PH>(r.wptr, loff, cur, mid, r.a, b, acc);
+            bf16_tap<CIN, NT, PH + 2>(r.wptr, loff, mid, nxt, r.a, b, acc);
+            cur = nxt;
+        }
+        if (j < ks) bf16_tap<CIN, NT, PH>(r.wptr, loff, cur, cur, r.a, b, acc);  // the odd last tap: the ring ends 2 slots on
+    }
 }
 
 // Rb: wave-uniform first row of the wave's columns in the LDS tile (the lane's column is added inside)
@@ -662,7 +755,8 @@ __device__ __forceinline__ void store4_relu(float* p, float a, float b, float c,
 }
 __device__ __forceinline__ void store4_relu(__bf16* p, float a, float b, float c, float d) {
     typedef short s16x4 __attribute__((ext_vector_type(4)));
-    bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 v = {pk_bf16(a, b), pk_bf16(c, d)};
     s16x4 w = __builtin_bit_cast(s16x4, v);
     const s16x4 z = {0, 0, 0, 0};
     w = __builtin_elementwise_max(w, z);
@@ -678,9 +772,7 @@ __device__ __forceinline__ void store4_relu(__bf16* p, float a, float b, float c
 // 16 * (q & 1) + bcol, channels 16 mi + 4 (q & ~1) .. + 7, q = lane >> 4.
 __device__ __forceinline__ u32x4 pair_rows_bf16(const float (&x)[4], const float (&y)[4]) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    const bf16x4 bx = {(__bf16)x[0], (__bf16)x[1], (__bf16)x[2], (__bf16)x[3]};
-    const bf16x4 by = {(__bf16)y[0], (__bf16)y[1], (__bf16)y[2], (__bf16)y[3]};
-    const u32x2 ux = __builtin_bit_cast(u32x2, bx), uy = __builtin_bit_cast(u32x2, by);
+    const u32x2 ux = {pk_bf16(x[0], x[1]), pk_bf16(x[2], x[3])}, uy = {pk_bf16(y[0], y[1]), pk_bf16(y[2], y[3])};
     const u32x2 r0 = __builtin_amdgcn_permlane16_swap(ux[0], uy[0], false, false);
     const u32x2 r1 = __builtin_amdgcn_permlane16_swap(ux[1], uy[1], false, false);
     u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
@@ -695,12 +787,27 @@ __device__ __forceinline__ void init_acc_bias(Frag<DT> (&acc)[NT], const float* 
     float bv[4][4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) load4(cst + 32 * mt + F::chan(g, lane), bv[g]);
+    if constexpr (sizeof(DT) == 2) {
+        // 64-bit moves: half the VALU issue slots of 16 NT v_mov_b32 (the init is exposed once per layer and tile)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+            for (int g = 0; g < 4; ++g) {
+                const f32x2 lo = {bv[g][0], bv[g][1]}, hi = {bv[g][2], bv[g][3]};
+                f32x2 l2, h2;
+                asm volatile("v_mov_b64 %0, %1" : "=v"(l2) : "v"(lo));
+                asm volatile("v_mov_b64 %0, %1" : "=v"(h2) : "v"(hi));
+                acc[nt].v[g] = f32x4{l2[0], l2[1], h2[0], h2[1]};
+            }
+    } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[nt].set(g, i, bv[g][i]);
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[nt].set(g, i, bv[g][i]);
+    }
 }
 
 // relu(acc) of this wave's 32-channel x NT*32-column tile -> CH-channel LDS rows; row0 = LDS row of the wave's
@@ -774,6 +881,8 @@ struct BlockArgs {
     float* cmax;       // [B] or null: running max of the clipped CAM row (atomic max per head tile)
     int L, ks1, cam_row, tiles_per_window, total_tiles;
     const void* zero_row;  // ZPAD kernels: 512 B of zeros = what lies outside the window (classifiers/resnet.py:62)
+    const char* wstream;   // bf16: the block's A fragments as one stream per out-channel tile (WRing), wstride bytes apart
+    int wstride;
 };
 
 template <typename DT, int CIN, int NT, int NWC, int MTW = 1>
@@ -926,6 +1035,32 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
 #pragma unroll
         for (int m = 0; m < MTW; ++m) init_acc_bias<DT, NT>(acc[m], cst + 128 * layer, mt0 + m, lane);
     };
+    // bf16: one weight stream through all the layers of all the tiles (WRing); PH2 = the ring slot layers 2.. start on
+    constexpr bool STREAM = sizeof(DT) == 2;
+    static_assert(!STREAM || (MTW == 1 && ((CIN == 128 && !HAS_RES) || (CIN == 64 && HAS_RES))), "ring phases");
+    constexpr int PH2 = CIN == 64 ? 2 : 0;
+    const char* wbase = a.wstream + (size_t)mt0 * a.wstride;
+    WRing ring;
+    if constexpr (STREAM) ring_begin(ring, wbase, lane * 16);
+
+    // bf16 CAM head (below): the two head rows as a 16x16x32 A operand, rows 0 and 1, hi and lo bf16 halves
+    u32x4 head_hi = {0u, 0u, 0u, 0u}, head_lo = {0u, 0u, 0u, 0u};
+    if constexpr (HEAD && sizeof(DT) == 2) {
+        const int row = lane & 15, q = lane >> 4;
+        if (row < 2) {
+            float wa[4], wb[4], r[8];
+            load4(a.wfc + row * 128 + 32 * mt0 + 4 * q, wa);        // k-values 0..3 of k-block q: channels 4q..
+            load4(a.wfc + row * 128 + 32 * mt0 + 16 + 4 * q, wb);   // k-values 4..7: channels 16 + 4q..
+            const float w[8] = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                head_hi[j] = pk_bf16(w[2 * j], w[2 * j + 1]);
+                r[2 * j] = w[2 * j] - __uint_as_float(head_hi[j] << 16);
+                r[2 * j + 1] = w[2 * j + 1] - __uint_as_float(head_hi[j] & 0xffff0000u);
+                head_lo[j] = pk_bf16(r[2 * j], r[2 * j + 1]);
+            }
+        }
+    }
 
     __syncthreads();  // first X landed
     int it = 0;
@@ -940,7 +1075,8 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
         // ---- ConvBlock(k): X(P) -> A1(Q), rows = column + pad2 (3 for the 7-tap second layer)
         STAMP(0);
         start_acc(acc, 0);
-        mma_layer<DT, CIN, NT, MTW>(P, colw, ks1, w1, acc);
+        if constexpr (STREAM) mma_stream_bf16<CIN, NT, 0, false>(P, colw, ks1, ring, acc[0], nullptr);
+        else mma_layer<DT, CIN, NT, MTW>(P, colw, ks1, w1, acc);
         STAMP(1);
 #pragma unroll
         for (int m = 0; m < MTW; ++m) store_act_lds<DT, NT>(Q, colw + pad2, acc[m], mt0 + m, opaque(lane));
@@ -953,7 +1089,8 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
         STAMP(3);
         // ---- ConvBlock(7 | 5): A1(Q) -> A2(P), rows = column + 1
         start_acc(acc, 1);
-        mma_layer<DT, 128, NT, MTW>(Q, colw, ks2, w2, acc);
+        if constexpr (STREAM) mma_stream_bf16<128, NT, PH2, false>(Q, colw, ks2, ring, acc[0], nullptr);
+        else mma_layer<DT, 128, NT, MTW>(Q, colw, ks2, w2, acc);
         STAMP(4);
 #pragma unroll
         for (int m = 0; m < MTW; ++m) store_act_lds<DT, NT>(P, colw + 1, acc[m], mt0 + m, opaque(lane));
@@ -966,7 +1103,12 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
         STAMP(6);
         // ---- ConvBlock(3): A2(P) -> registers
         start_acc(acc, 2);
-        mma_layer<DT, 128, NT, MTW>(P, colw, 3, w3, acc);
+        if constexpr (STREAM) {
+            mma_stream_bf16<128, NT, PH2, false>(P, colw, 3, ring, acc[0], nullptr);
+            if constexpr (!HAS_RES) ring.wptr = wbase + 3 * 2048;  // the ring already holds the next tile's first 3 groups
+        } else {
+            mma_layer<DT, 128, NT, MTW>(P, colw, 3, w3, acc);
+        }
         STAMP(7);
 
         float bv[4][4];
@@ -984,8 +1126,13 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
                         for (int i = 0; i < 4; ++i) acc[m][nt].set(g, i, fmaxf(acc[m][nt].get(g, i), 0.f));
             if constexpr (HAS_RES) {
                 __syncthreads();  // BR: centre rows of X landed in Q + xb
-                const uint4* wr = a.wr + (size_t)mt0 * NCPI * 64;
-                mma_layer<DT, CIN, NT, MTW>(Q + xb, colw, 1, wr, acc);
+                if constexpr (STREAM) {
+                    mma_stream_bf16<CIN, NT, PH2, false>(Q + xb, colw, 1, ring, acc[0], nullptr);
+                    ring.wptr = wbase + 3 * 2048;  // the ring already holds the next tile's first 3 groups
+                } else {
+                    const uint4* wr = a.wr + (size_t)mt0 * NCPI * 64;
+                    mma_layer<DT, CIN, NT, MTW>(Q + xb, colw, 1, wr, acc);
+                }
             }
             DT* outp = reinterpret_cast<DT*>(a.out);
 #pragma unroll
@@ -1027,6 +1174,30 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
                         }
                 }
             }
+        } else if constexpr (sizeof(DT) == 2) {
+            // CAM head on the matrix core: per 16-column tile the two head rows' dot products over the wave's 32
+            // channels are ONE 16x16x32 MFMA whose B operand is the tile's accumulators themselves (relu, rounded
+            // to bf16: the lane's 8 channels 4q.. and 16 + 4q.. of its column are the 8 k-values of k-block q) and
+            // whose A operand holds the head rows in rows 0 and 1 (hi + lo bf16 halves: the weights stay exact to
+            // 2^-17) -- no per-element fma, no cross-lane reduction; lanes 0..15 hold rows 0 / 1 of their column.
+            const int mt = mt0;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int nj = 0; nj < 2; ++nj) {
+                    typedef short s16x8 __attribute__((ext_vector_type(8)));
+                    const f32x4 v0 = acc[0][nt].v[nj], v1 = acc[0][nt].v[2 + nj];
+                    const u32x4 raw = {pk_bf16(v0[0], v0[1]), pk_bf16(v0[2], v0[3]), pk_bf16(v1[0], v1[1]), pk_bf16(v1[2], v1[3])};
+                    const s16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+                    const bf16x8 bf = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, raw), z8));
+                    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, head_hi), bf, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, head_lo), bf, d, 0, 0, 0);
+                    if (le < 16) {
+                        const int c = colw + nt * 32 + F::col(nj, le);
+                        *reinterpret_cast<float2*>(red + (mt * N + c) * 2) = make_float2(d[0], d[1]);
+                    }
+                }
         } else {
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
@@ -1067,6 +1238,7 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
         __syncthreads();  // END
         STAMP(9);
     }
+    if constexpr (STREAM) ring_drain(ring);  // the last loads are still in flight
 }
 
 // ---------------------------------------------------------------------------------------

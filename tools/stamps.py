@@ -15,11 +15,12 @@ torch.cuda.synchronize()
 lib = C.CDLL(os.environ["CAMAL_HIP_LIB"])
 buf = np.zeros((256, 9, 18), np.uint64)
 assert lib.camal_debug_stamps(buf.ctypes.data_as(C.c_void_p)) == 0
-st = buf[:, :8, :10].astype(np.int64)       # compute waves
+NW = int(os.environ.get("NW", "8"))
+st = buf[:, :NW, :10].astype(np.int64)       # compute waves
 d = np.diff(st, axis=2)                     # [wg][wave][9]
 names = ["K1 conv k", "epi1 (LDS store)", "barrier B1", "K2 conv 7", "epi2", "barrier B2", "K3 conv 3", "head epilogue", "barrier END"]
 tot = (st[:, :, 9] - st[:, :, 0]).mean()
-print(f"k={k}: tile = {tot:.0f} cycles (mean over {st.shape[0]} workgroups x 8 waves)")
+print(f"k={k}: tile = {tot:.0f} cycles (mean over {st.shape[0]} workgroups x {NW} waves)")
 for i, n in enumerate(names):
     print(f"  {n:18s} mean {d[:, :, i].mean():8.0f}  min {d[:, :, i].min():7d}  max {d[:, :, i].max():7d}   {100 * d[:, :, i].mean() / tot:5.1f} %")
 mf = {5: 15, 7: 17, 9: 19, 15: 25, 25: 35}[k] * 4 * 16 * 16 * 2
