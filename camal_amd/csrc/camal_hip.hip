@@ -243,6 +243,9 @@ size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 #ifndef CAMAL_BF16_BLOCK_WAVES
 #define CAMAL_BF16_BLOCK_WAVES 4
 #endif
+#ifndef CAMAL_BF16_BLOCK1_WAVES
+#define CAMAL_BF16_BLOCK1_WAVES 8
+#endif
 template <typename DT> struct BlockNT;
 template <> struct BlockNT<float> { static constexpr int NT = 2; static constexpr int NWC = 8; };
 template <> struct BlockNT<__bf16> { static constexpr int NWC = CAMAL_BF16_BLOCK_WAVES; static constexpr int NT = 32 / NWC; };
@@ -473,7 +476,7 @@ int launch_block(camal_ctx* c, hipStream_t s, const Layer& l1, const Layer& l2, 
 // fused block 1: x [BC][L] -> block output [BC][L][64]
 template <typename DT, int NWC, bool VARIANT = false>
 int launch_block1_w(camal_ctx* c, hipStream_t s, const Member& m, const float* x, void* out, int BC, int L) {
-    constexpr int NTB = sizeof(DT) == 2 ? 4 : 2;  // column tiles per wave
+    constexpr int NTB = sizeof(DT) == 2 ? 32 / NWC : 2;  // column tiles per wave (bf16: 512-column tiles either way)
     using G = Block1Geom<DT, NTB, NWC>;
     auto kern = block1_kernel<DT, NTB, NWC, VARIANT ? 5 : 7, VARIANT>;
     if (m.conv[0].ks != (VARIANT ? 5 : 7) || m.conv[1].ks != 3) return fail(CAMAL_ERR_STATE, "fused block 1: unexpected layer kernel sizes");
@@ -501,8 +504,9 @@ int launch_block1_w(camal_ctx* c, hipStream_t s, const Member& m, const float* x
 // runs under the other's MFMAs: measured, no difference.)
 template <typename DT>
 int launch_block1(camal_ctx* c, hipStream_t s, const Member& m, const float* x, void* out, int BC, int L) {
-    if (c->arch == CAMAL_ARCH_RESNET) return launch_block1_w<DT, 8, true>(c, s, m, x, out, BC, L);
-    return launch_block1_w<DT, 8>(c, s, m, x, out, BC, L);
+    constexpr int NWC = sizeof(DT) == 2 ? CAMAL_BF16_BLOCK1_WAVES : 8;
+    if (c->arch == CAMAL_ARCH_RESNET) return launch_block1_w<DT, NWC, true>(c, s, m, x, out, BC, L);
+    return launch_block1_w<DT, NWC>(c, s, m, x, out, BC, L);
 }
 
 // camal_forward_cam_tap with tap_block = 1: the CAM of block 2's output (in `feat`, [BC * L][CH]) into c->tap_cam

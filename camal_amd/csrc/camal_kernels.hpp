@@ -861,7 +861,7 @@ __device__ __forceinline__ void fix_edges(char* buf, int guard, int g, int c_fir
 // Diagnostic build only: s_memtime stamps of the second tile of every workgroup (block 3 kernel), per wave.
 #define CAMAL_NSTAMP 18
 __device__ unsigned long long g_stamps[256][9][CAMAL_NSTAMP];
-#define STAMP(i) do { if (HEAD && it == 1 && blockIdx.x < 256 && (threadIdx.x & 63) == 0) \
+#define STAMP(i) do { if ((CAMAL_STAMPS == 2 ? !HEAD : HEAD) && it == 1 && blockIdx.x < 256 && (threadIdx.x & 63) == 0) \
     g_stamps[blockIdx.x][threadIdx.x >> 6][i] = __builtin_amdgcn_s_memtime(); } while (0)
 #define STAMP1(i) do { if (it == 1 && blockIdx.x < 256 && (threadIdx.x & 63) == 0) \
     g_stamps[blockIdx.x][threadIdx.x >> 6][10 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
