@@ -400,7 +400,10 @@ __device__ __forceinline__ void mma_layer_bf16(const char* buf, int Rb, int ks, 
     }
     unsigned cur = b_addr<RB>(base, R0, q);
 #pragma unroll
-    for (int f = 0; f < NF; ++f) b[f] = lds_read16(cur + f * 16 * RB);
+    for (int f = 0; f < NF; ++f) {  // issue order pinned: see mma_stream_bf16
+        b[f] = lds_read16(cur + f * 16 * RB);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     if constexpr (NG == 4) {
 #pragma unroll 1
         for (int j = 0; j < ks; ++j) {
@@ -468,8 +471,14 @@ __device__ __forceinline__ void mma_stream_bf16(const char* buf, int Rb, int ks,
     }
     u32x4 b[NF];
     unsigned cur = b_addr<RB>(base, R0, q);
+    // in fragment order, pinned: the waits hipcc puts in the loop come from the issue order it merges at the loop
+    // header, and with these reads left to its scheduler fragment 0 was issued second to last: lgkmcnt(1), a full
+    // LDS round trip, at the top of every tap
 #pragma unroll
-    for (int f = 0; f < NF; ++f) b[f] = lds_read16(cur + f * 16 * RB);
+    for (int f = 0; f < NF; ++f) {
+        b[f] = lds_read16(cur + f * 16 * RB);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     if constexpr (NG == 4) {
         int j = 0;
         if constexpr (BIAS) {
