@@ -114,6 +114,21 @@ __device__ __forceinline__ void store4(__bf16* p, float a, float b, float c, flo
     const u32x2 v = {pk_bf16(a, b), pk_bf16(c, d)};
     *reinterpret_cast<u32x2*>(p) = v;
 }
+// relu of 4 values, stored in the activation type.  bf16: round first, then clamp the packed pairs as signed
+// 16-bit integers (a negative bf16 is a negative int16; -0 and negative NaNs become +0 like everything below 0)
+__device__ __forceinline__ void store4_relu(float* p, float a, float b, float c, float d) {
+    store4(p, fmaxf(a, 0.f), fmaxf(b, 0.f), fmaxf(c, 0.f), fmaxf(d, 0.f));
+}
+__device__ __forceinline__ void store4_relu(__bf16* p, float a, float b, float c, float d) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 v = {pk_bf16(a, b), pk_bf16(c, d)};
+    s16x4 w = __builtin_bit_cast(s16x4, v);
+    const s16x4 z = {0, 0, 0, 0};
+    w = __builtin_elementwise_max(w, z);
+    *reinterpret_cast<s16x4*>(p) = w;
+}
+
 __device__ __forceinline__ void load4(const float* p, float (&v)[4]) {
     float4 t = *reinterpret_cast<const float4*>(p);
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
@@ -335,11 +350,16 @@ template <int N> __device__ __forceinline__ void w_wait2(u32x4& r0, u32x4& r1) {
 
 // group in ring slot S (mod 4): issue the loads of the group 3 ahead, wait for this group's fragments, 2 MFMAs per B
 // fragment, each followed by the read of the next group's fragment (at LDS address bnext) into the same registers.
-// FIRST: the layer's first group: the accumulators START as mfma(a, b, bias fragment of the lane's 4 channels), so
-// a layer costs no accumulator initialisation (128 v_mov per wave and layer at NT = 8 otherwise).
-template <int RB, int NT, int S, bool FIRST = false>
+// LAST: the layer's last group.  Nothing is left to read; instead the epilogue of fragment f - 1 (whose two
+// accumulator tiles are final) is issued behind the MFMAs on fragment f: an epilogue is VALU and LDS-store work that
+// the matrix pipe would otherwise sit out (1.85 k cycles per layer and tile after a 512-cycle group).
+struct NoEpi {
+    static constexpr bool active = false;
+    template <int NT> __device__ __forceinline__ void operator()(int, Frag<__bf16> (&)[NT]) const {}
+};
+template <int RB, int NT, int S, bool LAST = false, typename Epi = NoEpi>
 __device__ __forceinline__ void bf16_group(const char*& wptr, unsigned loff, unsigned bnext, u32x4 (&a)[4][2],
-                                           u32x4 (&b)[2 * NT], Frag<__bf16> (&acc)[NT], const f32x4* bias = nullptr) {
+                                           u32x4 (&b)[2 * NT], Frag<__bf16> (&acc)[NT], const Epi& epi = Epi()) {
     constexpr int NF = 2 * NT, SL = S % 4;
     w_load2(a[(SL + 3) % 4][0], a[(SL + 3) % 4][1], wptr, loff);
     wptr += 2048;
@@ -351,9 +371,14 @@ __device__ __forceinline__ void bf16_group(const char*& wptr, unsigned loff, uns
         for (int mi = 0; mi < 2; ++mi)
             acc[f >> 1].v[2 * mi + (f & 1)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                 *reinterpret_cast<const bf16x8*>(&a[SL][mi]), *reinterpret_cast<const bf16x8*>(&b[f]),
-                FIRST ? bias[mi] : acc[f >> 1].v[2 * mi + (f & 1)], 0, 0, 0);
+                acc[f >> 1].v[2 * mi + (f & 1)], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        b[f] = lds_read16(bnext + f * 16 * RB);
+        if constexpr (!LAST) b[f] = lds_read16(bnext + f * 16 * RB);
+        else if (f > 0) epi(f - 1, acc);
+    }
+    if constexpr (LAST) {
+        __builtin_amdgcn_sched_barrier(0);
+        epi(NF - 1, acc);
     }
 }
 
@@ -364,17 +389,18 @@ __device__ __forceinline__ unsigned b_addr(unsigned base, int row, int q) {
 }
 
 // the NG groups of one tap, first ring slot S0: cur / nxt = b_addr of this tap / of the tap that follows
-template <int CIN, int NT, int S0, bool FIRST = false>
+// (LAST: the layer's last tap, see bf16_group)
+template <int CIN, int NT, int S0, bool LAST = false, typename Epi = NoEpi>
 __device__ __forceinline__ void bf16_tap(const char*& wptr, unsigned loff, unsigned cur, unsigned nxt, u32x4 (&a)[4][2],
-                                         u32x4 (&b)[2 * NT], Frag<__bf16> (&acc)[NT], const f32x4* bias = nullptr) {
+                                         u32x4 (&b)[2 * NT], Frag<__bf16> (&acc)[NT], const Epi& epi = Epi()) {
     constexpr int RB = CIN * 2, NG = CIN / 32;
-    bf16_group<RB, NT, S0, FIRST>(wptr, loff, cur ^ (1u << 6), a, b, acc, bias);
+    bf16_group<RB, NT, S0>(wptr, loff, cur ^ (1u << 6), a, b, acc);
     if constexpr (NG == 2) {
-        bf16_group<RB, NT, S0 + 1>(wptr, loff, nxt, a, b, acc);
+        bf16_group<RB, NT, S0 + 1, LAST, Epi>(wptr, loff, nxt, a, b, acc, epi);
     } else {
         bf16_group<RB, NT, S0 + 1>(wptr, loff, cur ^ (2u << 6), a, b, acc);
         bf16_group<RB, NT, S0 + 2>(wptr, loff, cur ^ (3u << 6), a, b, acc);
-        bf16_group<RB, NT, S0 + 3>(wptr, loff, nxt, a, b, acc);
+        bf16_group<RB, NT, S0 + 3, LAST, Epi>(wptr, loff, nxt, a, b, acc, epi);
     }
 }
 
@@ -451,24 +477,21 @@ __device__ __forceinline__ void ring_drain(WRing& r) {
     for (int d = 0; d < 4; ++d) w_wait2<0>(r.a[d][0], r.a[d][1]);
 }
 
-// One layer off the running ring.  BIAS: the accumulators start from the layer's bias (bias_lds = the LDS copy of
-// the wave's 32 bias values), through the C operand of the first group's MFMAs; else the products add to acc.
-template <int CIN, int NT, int PH, bool BIAS>
+// One layer off the running ring: the products add to acc.  Epi (optional): the layer's epilogue, called once per B
+// fragment f = 0 .. 2 NT - 1 from inside the last group (bf16_group LAST) when the two accumulator tiles
+// acc[f >> 1].v[(f & 1)], .v[2 + (f & 1)] are final; with 64 input channels the kernel size must then be odd.
+template <int CIN, int NT, int PH, typename Epi = NoEpi>
 __device__ __forceinline__ void mma_stream_bf16(const char* buf, int Rb, int ks, WRing& r, Frag<__bf16> (&acc)[NT],
-                                                const float* bias_lds) {
+                                                const Epi& epi = Epi()) {
     constexpr int RB = CIN * 2, NG = CIN / 32;
     static_assert(NG == 2 || NG == 4, "64 or 128 input channels");
     constexpr int NF = 2 * NT;
+    constexpr bool EPI = Epi::active;
     const int lane = threadIdx.x & 63;
     const unsigned loff = lane * 16;
     const int q = Frag<__bf16>::kblock(lane);
     const int R0 = Rb + Frag<__bf16>::bcol(lane);
     const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)buf;
-    f32x4 bias[2];
-    if constexpr (BIAS) {
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) bias[mi] = *reinterpret_cast<const f32x4*>(bias_lds + 16 * mi + 4 * (lane >> 4));
-    }
     u32x4 b[NF];
     unsigned cur = b_addr<RB>(base, R0, q);
     // in fragment order, pinned: the waits hipcc puts in the loop come from the issue order it merges at the loop
@@ -480,29 +503,16 @@ __device__ __forceinline__ void mma_stream_bf16(const char* buf, int Rb, int ks,
         __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (NG == 4) {
-        int j = 0;
-        if constexpr (BIAS) {
-            const unsigned nxt = 1 < ks ? b_addr<RB>(base, R0 + 1, q) : cur;
-            bf16_tap<CIN, NT, PH, true>(r.wptr, loff, cur, nxt, r.a, b, acc, bias);
-            cur = nxt;
-            j = 1;
-        }
+        const int body = EPI ? ks - 1 : ks;
 #pragma unroll 1
-        for (; j < ks; ++j) {
+        for (int j = 0; j < body; ++j) {
             const unsigned nxt = j + 1 < ks ? b_addr<RB>(base, R0 + j + 1, q) : cur;  // past the end: any valid address
             bf16_tap<CIN, NT, PH>(r.wptr, loff, cur, nxt, r.a, b, acc);
             cur = nxt;
         }
+        if constexpr (EPI) bf16_tap<CIN, NT, PH, true, Epi>(r.wptr, loff, cur, cur, r.a, b, acc, epi);
     } else {
         int j = 0;
-        if constexpr (BIAS) {  // ks >= 2
-            const unsigned mid = b_addr<RB>(base, R0 + 1, q);
-            const unsigned nxt = 2 < ks ? b_addr<RB>(base, R0 + 2, q) : mid;
-            bf16_tap<CIN, NT, PH, true>(r.wptr, loff, cur, mid, r.a, b, acc, bias);
-            bf16_tap<CIN, NT, PH + 2>(r.wptr, loff, mid, nxt, r.a, b, acc);
-            cur = nxt;
-            j = 2;
-        }
 #pragma unroll 1
         for (; j + 2 <= ks; j += 2) {  // two taps = 4 groups per body: static ring slots
             const unsigned mid = b_addr<RB>(base, R0 + j + 1, q);
@@ -511,9 +521,41 @@ __device__ __forceinline__ void mma_stream_bf16(const char* buf, int Rb, int ks,
             bf16_tap<CIN, NT, PH + 2>(r.wptr, loff, mid, nxt, r.a, b, acc);
             cur = nxt;
         }
-        if (j < ks) bf16_tap<CIN, NT, PH>(r.wptr, loff, cur, cur, r.a, b, acc);  // the odd last tap: the ring ends 2 slots on
+        // the odd last tap: the ring ends 2 slots on
+        if (EPI || j < ks) bf16_tap<CIN, NT, PH, EPI, Epi>(r.wptr, loff, cur, cur, r.a, b, acc, epi);
     }
 }
+
+// Epi of a layer whose output goes on to the next layer through LDS: relu(acc) of fragment f -> CH-channel LDS rows,
+// what store_act_lds does for the whole tile (same addresses: one per (column half nj, channel half mi), the column
+// tiles are constant offsets from them).
+template <int NT, int CH = 128>
+struct ActStoreEpi {
+    static constexpr bool active = true;
+    char* pg[2][2];
+    __device__ __forceinline__ ActStoreEpi(char* dst, int row0, int mt, int lane) {
+        using F = Frag<__bf16>;
+        constexpr int RB = CH * 2, CPR = RB / 16;
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int g = 2 * mi + nj;
+                const int row = row0 + F::col(g, lane);
+                const int boff = (32 * mt + F::chan(g, lane)) * 2;
+                pg[nj][mi] = dst + row * RB + (((boff >> 4) ^ swz<CPR>(row)) << 4) + (boff & 15);
+            }
+    }
+    __device__ __forceinline__ void operator()(int f, Frag<__bf16> (&acc)[NT]) const {
+        constexpr int RB = CH * 2;
+        const int nt = f >> 1, nj = f & 1;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const f32x4 v = acc[nt].v[2 * mi + nj];
+            store4_relu(reinterpret_cast<__bf16*>(pg[nj][mi] + nt * 32 * RB), v[0], v[1], v[2], v[3]);
+        }
+    }
+};
 
 // Rb: wave-uniform first row of the wave's columns in the LDS tile (the lane's column is added inside)
 template <typename DT, int CIN, int NT, int MTW = 1>
@@ -757,21 +799,6 @@ __global__ __launch_bounds__((NWC + 1) * 64) void conv_kernel(const DT* __restri
 //     rectified accumulator, so no second accumulator is needed.
 //   HEAD (block 3): CAM head as in conv_kernel; the 128 x L feature map is never written.
 // ---------------------------------------------------------------------------------------
-// relu of 4 values, stored in the activation type.  bf16: round first, then clamp the packed pairs as signed
-// 16-bit integers (a negative bf16 is a negative int16; -0 and negative NaNs become +0 like everything below 0)
-__device__ __forceinline__ void store4_relu(float* p, float a, float b, float c, float d) {
-    store4(p, fmaxf(a, 0.f), fmaxf(b, 0.f), fmaxf(c, 0.f), fmaxf(d, 0.f));
-}
-__device__ __forceinline__ void store4_relu(__bf16* p, float a, float b, float c, float d) {
-    typedef short s16x4 __attribute__((ext_vector_type(4)));
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    const u32x2 v = {pk_bf16(a, b), pk_bf16(c, d)};
-    s16x4 w = __builtin_bit_cast(s16x4, v);
-    const s16x4 z = {0, 0, 0, 0};
-    w = __builtin_elementwise_max(w, z);
-    *reinterpret_cast<s16x4*>(p) = w;
-}
-
 // bf16 output rows in 16-byte stores: a lane holds, for the fragment pair (mi, nj = 0 / 1), 4 channels (8 bytes) of
 // column bcol and of column 16 + bcol; lanes l and l ^ 16 hold neighbouring 4-channel groups.  One
 // v_permlane16_swap per dword hands the even k-block rows the neighbour's half of column nj = 0 and the odd ones
@@ -1084,11 +1111,16 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
         // ---- ConvBlock(k): X(P) -> A1(Q), rows = column + pad2 (3 for the 7-tap second layer)
         STAMP(0);
         start_acc(acc, 0);
-        if constexpr (STREAM) mma_stream_bf16<CIN, NT, 0, false>(P, colw, ks1, ring, acc[0], nullptr);
-        else mma_layer<DT, CIN, NT, MTW>(P, colw, ks1, w1, acc);
-        STAMP(1);
+        if constexpr (STREAM) {  // the LDS-store epilogue rides inside the last group of the K loop
+            const ActStoreEpi<NT> epi(Q, colw + pad2, mt0, opaque(lane));
+            mma_stream_bf16<CIN, NT, 0>(P, colw, ks1, ring, acc[0], epi);
+            STAMP(1);
+        } else {
+            mma_layer<DT, CIN, NT, MTW>(P, colw, ks1, w1, acc);
+            STAMP(1);
 #pragma unroll
-        for (int m = 0; m < MTW; ++m) store_act_lds<DT, NT>(Q, colw + pad2, acc[m], mt0 + m, opaque(lane));
+            for (int m = 0; m < MTW; ++m) store_act_lds<DT, NT>(Q, colw + pad2, acc[m], mt0 + m, opaque(lane));
+        }
         STAMP(2);
         __syncthreads();  // B1
         if (lo || hi) {
@@ -1098,11 +1130,16 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
         STAMP(3);
         // ---- ConvBlock(7 | 5): A1(Q) -> A2(P), rows = column + 1
         start_acc(acc, 1);
-        if constexpr (STREAM) mma_stream_bf16<128, NT, PH2, false>(Q, colw, ks2, ring, acc[0], nullptr);
-        else mma_layer<DT, 128, NT, MTW>(Q, colw, ks2, w2, acc);
-        STAMP(4);
+        if constexpr (STREAM) {
+            const ActStoreEpi<NT> epi(P, colw + 1, mt0, opaque(lane));
+            mma_stream_bf16<128, NT, PH2>(Q, colw, ks2, ring, acc[0], epi);
+            STAMP(4);
+        } else {
+            mma_layer<DT, 128, NT, MTW>(Q, colw, ks2, w2, acc);
+            STAMP(4);
 #pragma unroll
-        for (int m = 0; m < MTW; ++m) store_act_lds<DT, NT>(P, colw + 1, acc[m], mt0 + m, opaque(lane));
+            for (int m = 0; m < MTW; ++m) store_act_lds<DT, NT>(P, colw + 1, acc[m], mt0 + m, opaque(lane));
+        }
         STAMP(5);
         __syncthreads();  // B2
         if (lo || hi) {
@@ -1113,7 +1150,7 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
         // ---- ConvBlock(3): A2(P) -> registers
         start_acc(acc, 2);
         if constexpr (STREAM) {
-            mma_stream_bf16<128, NT, PH2, false>(P, colw, 3, ring, acc[0], nullptr);
+            mma_stream_bf16<128, NT, PH2>(P, colw, 3, ring, acc[0]);
             if constexpr (!HAS_RES) ring.wptr = wbase + 3 * 2048;  // the ring already holds the next tile's first 3 groups
         } else {
             mma_layer<DT, 128, NT, MTW>(P, colw, 3, w3, acc);
@@ -1136,7 +1173,7 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
             if constexpr (HAS_RES) {
                 __syncthreads();  // BR: centre rows of X landed in Q + xb
                 if constexpr (STREAM) {
-                    mma_stream_bf16<CIN, NT, PH2, false>(Q + xb, colw, 1, ring, acc[0], nullptr);
+                    mma_stream_bf16<CIN, NT, PH2>(Q + xb, colw, 1, ring, acc[0]);
                     ring.wptr = wbase + 3 * 2048;  // the ring already holds the next tile's first 3 groups
                 } else {
                     const uint4* wr = a.wr + (size_t)mt0 * NCPI * 64;
@@ -1189,6 +1226,8 @@ __global__ __launch_bounds__((NWC + 1) * 64) void block_kernel(BlockArgs a) {
             // to bf16: the lane's 8 channels 4q.. and 16 + 4q.. of its column are the 8 k-values of k-block q) and
             // whose A operand holds the head rows in rows 0 and 1 (hi + lo bf16 halves: the weights stay exact to
             // 2^-17) -- no per-element fma, no cross-lane reduction; lanes 0..15 hold rows 0 / 1 of their column.
+            // (Issued from inside the last group of the K loop, like the LDS-store epilogues: measured slower,
+            // 15.2 -> 15.8 ms per step, the hi -> lo MFMA pairs are dependent and the registers spill.)
             const int mt = mt0;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)

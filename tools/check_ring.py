@@ -26,12 +26,30 @@ def regs(tok):
 def check(path):
     findings = []
     kernel, pending, inasm, prev = None, set(), False, ""
+    # The scan follows the text; blocks the compiler moved out of line (cold paths at the end of a kernel) are
+    # entered with the loads that were in flight at the forward branches that reach them, not with whatever the
+    # text in front of them left: at_branch[label] = union over those branches, falls = the previous line falls through.
+    at_branch, falls = {}, True
     for n, line in enumerate(open(path), 1):
         t = line.strip()
         if t.startswith(".amdhsa_kernel") or (t.endswith(":") and t.startswith("_Z") and "camal" in t):
             if t.endswith(":"):
-                kernel, pending = t[:-1], set()
+                kernel, pending, at_branch, falls = t[:-1], set(), {}, True
             continue
+        if t.startswith(".LBB") and ":" in t:
+            label = t.split(":")[0]
+            pending = (set(pending) if falls else set()) | at_branch.get(label, set())
+            falls = True
+            continue
+        if t.startswith("s_cbranch") or t.startswith("s_branch"):
+            target = t.split()[1]
+            at_branch[target] = at_branch.get(target, set()) | pending
+            if t.startswith("s_branch"):
+                falls = False
+            prev = t
+            continue
+        if t.startswith("s_endpgm") or t.startswith("s_setpc"):
+            falls = False
         if "ASMSTART" in t:
             inasm = True
             continue
