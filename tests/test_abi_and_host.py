@@ -204,6 +204,33 @@ def test_hand_counted_weight_ring_is_untouched_by_the_compiler(tmp_path):
     assert check_ring.check(str(asm)) == []
 
 
+def test_ring_checker_sees_hazards_and_follows_out_of_line_blocks(tmp_path):
+    """The checker itself, on hand-written assembly: a compiler-made instruction that touches a register with a
+    ring load in flight is reported, on the straight path and in a block the compiler moved behind the kernel's end
+    (entered with what was in flight at the branch, not with what the text in front of it left); the same block is
+    clean when the branch leaves after the consuming MFMA."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_ring
+    load = ("\t;;#ASMSTART\n\ts_mov_b64 s[4:5], s[2:3]\n\tglobal_load_dwordx4 v[10:13], v1, s[4:5]\n\t;;#ASMEND\n")
+    mfma = "\tv_mfma_f32_16x16x32_bf16 v[40:43], v[10:13], v[20:23], v[40:43]\n"
+    tail = "\ts_endpgm\n.LBB0_9:\n\tds_read_b128 v[10:13], v2\n\ts_branch .LBB0_2\n"
+
+    def run(body):
+        f = tmp_path / "k.s"
+        f.write_text("_ZN5camal4testEv:\n" + body)
+        return check_ring.check(str(f))
+
+    assert run(load + mfma + "\tv_mov_b32_e32 v10, 0\n\ts_endpgm\n") == []
+    assert len(run(load + "\tv_mov_b32_e32 v10, 0\n" + mfma + "\ts_endpgm\n")) == 1
+    # out-of-line block reached while the load is in flight: a finding, although the text in front of it ends clean
+    assert len(run(load + "\ts_cbranch_vccz .LBB0_9\n.LBB0_2:\n" + mfma + tail)) == 1
+    # reached after the consumer: clean
+    assert run(load + mfma + "\ts_cbranch_vccz .LBB0_9\n.LBB0_2:\n" + tail) == []
+    # a load whose scalar base does not come from the s_mov_b64 in front of it
+    assert len(run("\t;;#ASMSTART\n\tglobal_load_dwordx4 v[10:13], v1, s[4:5]\n\t;;#ASMEND\n" + mfma + "\ts_endpgm\n")) == 1
+
+
 def test_bench_spawns_its_own_ranks_dry_run():
     """`python bench.py --gpus 2` without a launcher: the parent starts the two ranks as children (before anything
     touches a GPU) and rank 0's line comes through; --dry-run rehearses that path on CPU with gloo."""
