@@ -203,12 +203,16 @@ def train_case(name, k, seed, n, length, batch, epochs, lr=1e-3, arch=weights.AR
           f"acc={np.round(tr.accuracy_train_history, 3).tolist()} size={os.path.getsize(os.path.join(HERE, name + '.npz')) / 1024:.0f} KB")
 
 
-def big_ensemble_case(name="cfg0_l1024", n=64, length=1024, data_seed=0, seed=107, gain=2.0):
+def big_ensemble_case(name="cfg0_l1024", n=64, length=1024, data_seed=0, seed=107, gain=2.0, members=None, refit=False):
     """BASELINE configs[0] at full size through the reference's own CamAL.predict (E=5, k=5,7,9,15,25, 64 x 1024
     UK-DALE-shaped windows, data seed 0): the windows come back from the seed, the states are stored as int8, the
-    per-member CAMs and the averaged CAM at every 8th timestamp."""
-    data = synth.ukdale_windows(n, length, seed=data_seed)
+    per-member CAMs and the averaged CAM at every 8th timestamp.  (members / refit: the configs[4] week windows,
+    L = 10080 REFIT-shaped, on a few windows and two members.)"""
+    KERNELS = members or globals()["KERNELS"]
+    data = (synth.refit_windows if refit else synth.ukdale_windows)(n, length, seed=data_seed)
     gains, biases = calibrate_heads(data, seed, gain)
+    gains = [gains[globals()["KERNELS"].index(k)] for k in KERNELS]
+    biases = [biases[globals()["KERNELS"].index(k)] for k in KERNELS]
     sds = [weights.make_state_dict(k, seed=seed, head_gain=g, head_bias=b) for k, g, b in zip(KERNELS, gains, biases)]
     cams = np.zeros((len(KERNELS), n, length), np.float32)
     labels = np.zeros((len(KERNELS), n), np.int32)
@@ -520,6 +524,8 @@ def main():
         return width_cases()
     if len(sys.argv) > 1 and sys.argv[1] == "cfg0":
         return big_ensemble_case()
+    if len(sys.argv) > 1 and sys.argv[1] == "week":
+        return big_ensemble_case("week_l10080", n=6, length=10080, data_seed=4, seed=131, gain=2.0, members=[5, 25], refit=True)
     if len(sys.argv) > 1 and sys.argv[1] == "control":
         return trainer_control_flow_case()
     if len(sys.argv) > 1 and sys.argv[1] == "trainvalid":
@@ -529,6 +535,7 @@ def main():
     width_cases()
     camtap_case()
     big_ensemble_case()
+    big_ensemble_case("week_l10080", n=6, length=10080, data_seed=4, seed=131, gain=2.0, members=[5, 25], refit=True)
     trainer_control_flow_case()
     trainer_valid_case()
     train_case("train_k7_l510", k=7, seed=205, n=128, length=510, batch=128, epochs=1)

@@ -149,6 +149,36 @@ def test_config0_full_size_vs_reference_fixture(torch_cuda):
     e16.close()
 
 
+def test_config4_week_windows_vs_reference_fixture(torch_cuda):
+    """configs[4]'s length (L = 10080) against what the REFERENCE returned (tests/golden/week_l10080.npz: 6 REFIT-shaped
+    windows, members k = 5 and 25): fp32 probabilities, CAM samples, averaged CAM and states; bf16 states on every window
+    (none of them votes within 0.2 of the threshold)."""
+    from camal_amd import synth
+    from camal_amd.engine import Ensemble
+    from tests.helpers import case_state_dicts, load_case
+    c = load_case("week_l10080")
+    sds = case_state_dicts(c)
+    x = synth.refit_windows(int(c["n"]), int(c["length"]), seed=int(c["data_seed"]))
+    st = int(c["cam_stride"])
+    ens = Ensemble(sds, device="cuda:0", precision="fp32")
+    res = ens.localize(x, want_avg_cam=True, want_members=True)
+    prob, state = res["prob"].cpu().numpy(), res["state"].cpu().numpy()
+    assert np.abs(prob - c["prob_detect"][:, 0]).max() < REL_TOL_FP32
+    mcam = res["member_cam"].cpu().numpy()
+    for e in range(len(sds)):
+        err = np.abs(mcam[e][:, ::st] - c["cams_strided"][e]).max(axis=-1) / np.abs(c["cam_row_max"][e])
+        assert err.max() < REL_TOL_FP32, (e, err.max())
+    assert np.abs(c["prob_detect"][:, 0] - 0.5).min() > 0.2
+    assert np.abs(res["avg_cam"].cpu().numpy()[:, ::st] - c["avg_cam_strided"]).max() < REL_TOL_FP32
+    assert (state == c["states"]).mean() >= STATE_AGREE_MIN and (c["states"] != 0).sum() > 100
+    ens.close()
+    e16 = Ensemble(sds, device="cuda:0", precision="bf16")
+    r16 = e16.localize(x)
+    assert np.abs(r16["prob"].cpu().numpy() - c["prob_detect"][:, 0]).max() < 2e-2
+    assert (r16["state"].cpu().numpy() == c["states"]).mean() >= STATE_AGREE_MIN
+    e16.close()
+
+
 def test_config2_fp32_ensemble_sample_vs_oracle_and_bf16_all_windows(torch_cuda):
     """configs[2] shape (E=5, 1024 x 1440): the fp32 ensemble against the ORACLE on a spread sample of windows (not a
     self-comparison), then the bf16 path against fp32 over ALL timestamps of ALL windows whose fp32 vote is >= 2e-3

@@ -194,3 +194,28 @@ def test_cfg0_full_size_matches_reference():
         cams, labels, probs = outs[e]
         assert np.abs(cams[:, ::st] - c["cams_strided"][e][idx]).max() < REL_TOL_FP32 * np.abs(c["cam_row_max"][e][idx]).max()
         assert np.abs(probs - c["probs"][e][idx]).max() < REL_TOL_FP32
+
+
+def test_week_windows_match_reference():
+    """BASELINE configs[4]'s length (L = 10080, a week at 1 min) on 6 REFIT-shaped windows and two members (k = 5, 25;
+    tests/golden/week_l10080.npz = the reference's CAM.run and CamAL.predict): the torch restatement and the NumPy
+    oracle on the first two windows (the oracle's plain loops take their time at this length)."""
+    from camal_amd import synth
+    from oracle import torch_path
+    c = load_case("week_l10080")
+    sds = case_state_dicts(c)
+    x = synth.refit_windows(int(c["n"]), int(c["length"]), seed=int(c["data_seed"]))
+    states, prob = torch_path.predict_loop(sds, x)
+    assert np.abs(prob - c["prob_detect"]).max() < 1e-6
+    assert (states == c["states"]).mean() >= 0.9999 and (c["states"] != 0).sum() > 100
+    idx = np.arange(2)
+    s2, p2, avg, outs = oracle.camal_predict(sds, x[idx], return_intermediate=True)
+    st = int(c["cam_stride"])
+    assert np.abs(p2 - c["prob_detect"][idx]).max() < REL_TOL_FP32
+    assert (s2 == c["states"][idx]).mean() >= 0.999
+    assert np.abs(avg[:, ::st] - c["avg_cam_strided"][idx]).max() < REL_TOL_FP32
+    for e in range(len(sds)):
+        cams, labels, probs = outs[e]
+        assert np.abs(cams[:, ::st] - c["cams_strided"][e][idx]).max() < REL_TOL_FP32 * np.abs(c["cam_row_max"][e][idx]).max()
+        assert np.abs(probs - c["probs"][e][idx]).max() < REL_TOL_FP32
+
