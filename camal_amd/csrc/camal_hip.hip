@@ -250,7 +250,8 @@ template <typename DT> struct BlockNT;
 template <> struct BlockNT<float> { static constexpr int NT = 2; static constexpr int NWC = 8; };
 template <> struct BlockNT<__bf16> { static constexpr int NWC = CAMAL_BF16_BLOCK_WAVES; static constexpr int NT = 32 / NWC; };
 
-// wave = 32 out-channels x NT column tiles; NWC = 8: two column groups
+// wave = 32 out-channels x NT column tiles; fp32: NWC = 8, two column groups of 64; bf16: NWC = 4, one wave per SIMD
+// over all 256 columns (BlockNT)
 template <typename DT, int CIN, int NWC>
 using BGeom = BlockGeom<DT, CIN, BlockNT<DT>::NT, NWC, 1>;
 
@@ -261,10 +262,11 @@ size_t block_lds(int k) {
     return 2 * (size_t)G::buf_bytes(k, HAS_RES) + (HEAD ? G::HEAD_BYTES : 0) + G::CST_FLOATS * sizeof(float);
 }
 
-// One workgroup per CU: 8 compute waves (wave = 32 channels x half the columns) + the loader wave; 256-column
-// tiles in bf16, 128 in fp32.  0: the tile does not fit the LDS for this first kernel size.
+// One workgroup per CU: the compute waves of BlockNT<DT> + the loader wave; 256-column tiles in bf16 (4 waves of
+// 32 channels x 256 columns: two waves of 128 columns per SIMD never shared the matrix pipe evenly and loaded every
+// weight fragment twice, -1.6 %), 128 in fp32 (8 waves).  0: the tile does not fit the LDS for this first kernel size.
 // (Two 4-wave workgroups of half the tile width per CU, so that one's epilogues and barriers run under the
-// other's MFMAs: measured again on the 16x16x32 kernels, 10 % slower.)
+// other's MFMAs: measured on the 16x16x32 kernels, 10 % slower.)
 template <typename DT, int CIN, bool HAS_RES, bool HEAD>
 int block_nwc(size_t lds_per_cu, int k) {
     return block_lds<DT, CIN, BlockNT<DT>::NWC, HAS_RES, HEAD>(k) > lds_per_cu ? 0 : BlockNT<DT>::NWC;

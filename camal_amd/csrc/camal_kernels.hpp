@@ -798,6 +798,10 @@ __global__ __launch_bounds__((NWC + 1) * 64) void conv_kernel(const DT* __restri
 //     of X beside the prefetch; the 1x1 product is accumulated by MFMA on top of the already
 //     rectified accumulator, so no second accumulator is needed.
 //   HEAD (block 3): CAM head as in conv_kernel; the 128 x L feature map is never written.
+// bf16 runs NWC = 4 (one wave per SIMD, wave = 32 out-channels x all N = 256 columns, NT = 8), takes its weights from
+// ONE stream per out-channel tile through all layers and tiles (WRing / mma_stream_bf16), issues the LDS-store
+// epilogues of the first two layers from inside their last K-loop group (ActStoreEpi) and computes the CAM head
+// by MFMA on the accumulators; fp32 runs NWC = 8 with a weight ring per layer (mma_layer).
 // ---------------------------------------------------------------------------------------
 // bf16 output rows in 16-byte stores: a lane holds, for the fragment pair (mi, nj = 0 / 1), 4 channels (8 bytes) of
 // column bcol and of column 16 + bcol; lanes l and l ^ 16 hold neighbouring 4-channel groups.  One
