@@ -580,6 +580,17 @@ __device__ __forceinline__ float clip_cam(float v) {
     return __float_as_uint(v) < 0x7f800000u ? v : 0.f;
 }
 
+#ifdef CAMAL_STAMPS
+// Diagnostic builds only: s_memtime stamps of one tile per workgroup and wave (tools/stamps*.py)
+#define CAMAL_NSTAMP 18
+__device__ unsigned long long g_stamps[256][9][CAMAL_NSTAMP];
+// CAMAL_STAMPS == 3: the fp32 per-layer kernel of the 128 -> 128, k = 3 ConvBlock with the skip add (tools/stamps_conv.py)
+#define CSTAMP(i) do { if (CAMAL_STAMPS == 3 && sizeof(DT) == 4 && CIN == 128 && HAS_RES && it == 2 && blockIdx.x < 256 && (threadIdx.x & 63) == 0) \
+    g_stamps[blockIdx.x][threadIdx.x >> 6][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CSTAMP(i) do {} while (0)
+#endif
+
 template <typename DT, int CIN, int COUT, int NT, int NWC>
 struct ConvGeom {
     static constexpr int ES = sizeof(DT);
@@ -672,10 +683,12 @@ __global__ __launch_bounds__((NWC + 1) * 64) void conv_kernel(const DT* __restri
 
         F accw[1][NT];
         F (&acc)[NT] = accw[0];
+        CSTAMP(0);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt].zero();
 
         mma_layer<DT, CIN, NT, 1>(buf, Rb, ks, wp, accw);
+        CSTAMP(1);
 
         // ---- epilogue.  acc[nt] group g: column t0 + Rb + 32 nt + col(g), channels 32 mt + chan(g) + 0..3
         if constexpr (!HEAD) {
@@ -776,7 +789,9 @@ __global__ __launch_bounds__((NWC + 1) * 64) void conv_kernel(const DT* __restri
                 if (cmax != nullptr && pm > 0.f) atomicMax(reinterpret_cast<unsigned int*>(cmax) + b, __float_as_uint(pm));
             }
         }
+        CSTAMP(2);
         __syncthreads();  // next tile landed (loader) and this buffer is free to refill
+        CSTAMP(3);
     }
 }
 
@@ -899,8 +914,6 @@ __device__ __forceinline__ void fix_edges(char* buf, int guard, int g, int c_fir
 
 #ifdef CAMAL_STAMPS
 // Diagnostic build only: s_memtime stamps of the second tile of every workgroup (block 3 kernel), per wave.
-#define CAMAL_NSTAMP 18
-__device__ unsigned long long g_stamps[256][9][CAMAL_NSTAMP];
 #define STAMP(i) do { if ((CAMAL_STAMPS == 2 ? !HEAD : HEAD) && it == 1 && blockIdx.x < 256 && (threadIdx.x & 63) == 0) \
     g_stamps[blockIdx.x][threadIdx.x >> 6][i] = __builtin_amdgcn_s_memtime(); } while (0)
 #define STAMP1(i) do { if (it == 1 && blockIdx.x < 256 && (threadIdx.x & 63) == 0) \
