@@ -186,6 +186,30 @@ def test_fused_blocks_equal_per_layer_kernels(torch_cuda, precision, L):
     b.close()
 
 
+@pytest.mark.parametrize("ks", [(3, 9), (7, 15), (31, 5)])
+def test_fused_bf16_weight_stream_over_many_tiles(torch_cuda, ks):
+    """More tiles than workgroups (300 windows x 3 tiles on 256 CUs): every workgroup of the fused bf16 kernels walks
+    several tiles, so the endless weight ring wraps from the last layer of a tile into the first layer of the next
+    (camal_kernels.hpp: WRing), for first kernel sizes that leave the ring on either slot phase; against the
+    per-layer kernels, whose ring restarts with every layer."""
+    from camal_amd import synth, weights
+    from camal_amd.engine import Ensemble
+    sds = [weights.make_state_dict(k, seed=23, head_gain=3.0) for k in ks]
+    x = synth.ukdale_windows(300, 500, seed=7)
+    a = Ensemble(sds, device="cuda:0", precision="bf16")
+    b = Ensemble(sds, device="cuda:0", precision="bf16")
+    a.set_fused(True)
+    b.set_fused(False)
+    la, ca = a.forward_cam(x)
+    lb, cb = b.forward_cam(x)
+    ca, cb = ca.cpu().numpy(), cb.cpu().numpy()
+    for e in range(len(ks)):
+        assert rel_err(ca[e], cb[e]) < 3e-2, (ks[e], rel_err(ca[e], cb[e]))
+    assert np.abs(la.cpu().numpy() - lb.cpu().numpy()).max() < 5e-2 * max(1.0, float(np.abs(lb.cpu().numpy()).max()))
+    a.close()
+    b.close()
+
+
 # ---- classifiers/resnet.py's ResNet (kernels 7/5/3, zero "same" padding) through camal_create_arch -----------------
 @pytest.mark.parametrize("name", golden_cases("resnetvar_"))
 def test_resnet_variant_fp32_vs_reference(torch_cuda, name):
