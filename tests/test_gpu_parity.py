@@ -186,7 +186,7 @@ def test_fused_blocks_equal_per_layer_kernels(torch_cuda, precision, L):
     b.close()
 
 
-@pytest.mark.parametrize("ks", [(3, 9), (7, 15), (31, 5)])
+@pytest.mark.parametrize("ks", [(3, 9), (7, 15), (31, 5), "resnet"])
 def test_fused_bf16_weight_stream_over_many_tiles(torch_cuda, ks):
     """More tiles than workgroups (300 windows x 3 tiles on 256 CUs): every workgroup of the fused bf16 kernels walks
     several tiles, so the endless weight ring wraps from the last layer of a tile into the first layer of the next
@@ -194,7 +194,10 @@ def test_fused_bf16_weight_stream_over_many_tiles(torch_cuda, ks):
     per-layer kernels, whose ring restarts with every layer."""
     from camal_amd import synth, weights
     from camal_amd.engine import Ensemble
-    sds = [weights.make_state_dict(k, seed=23, head_gain=3.0) for k in ks]
+    if ks == "resnet":  # classifiers/resnet.py's blocks (7 / 5 / 3, zero padding): the other instantiation of the kernels
+        sds, ks = [weights.make_state_dict(7, seed=sd, arch=weights.ARCH_RESNET, head_gain=3.0) for sd in (23, 24)], (7, 7)
+    else:
+        sds = [weights.make_state_dict(k, seed=23, head_gain=3.0) for k in ks]
     x = synth.ukdale_windows(300, 500, seed=7)
     a = Ensemble(sds, device="cuda:0", precision="bf16")
     b = Ensemble(sds, device="cuda:0", precision="bf16")
