@@ -463,6 +463,14 @@ __global__ __launch_bounds__(256) void fold_edges_kernel(const float* __restrict
 // timesteps per staged tile: 64, or 32 for 256 out-channels (the dz tile must fit the 64 KiB of static LDS)
 template <int COUT> struct WgTT { static constexpr int V = COUT > 128 ? 32 : WG_TT; };
 
+// A prefetch hipcc's wait bookkeeping does not see (as the weight ring of the convolutions, camal_kernels.hpp w_load):
+// left to the compiler, the next tile's loads were followed by s_waitcnt vmcnt(10) -- the first of them back -- in front
+// of the MFMA loop they were meant to run under.  g_wait0 is the only wait; tools/check_ring.py watches the registers.
+__device__ __forceinline__ void g_load16(u32x4& d, const float* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void g_wait0(u32x4& d) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(d) : : "memory"); }
+
 template <int CIN, int COUT, int NTAP>
 __device__ __forceinline__ void wgrad_body(float (*s_dz)[COUT], float (*s_a)[32], const float* __restrict__ dz,
                                            const float* __restrict__ ain, float* __restrict__ part, int B, int L, int ks,
@@ -486,58 +494,97 @@ __device__ __forceinline__ void wgrad_body(float (*s_dz)[COUT], float (*s_a)[32]
     constexpr int DZ_PER = TT * (COUT / 4) / NTH;                  // = 8 float4 of dz per lane
     constexpr int A_Q = (TT + NTAP - 1) * 8, A_PER = (A_Q + NTH - 1) / NTH;
     static_assert(DZ_PER * NTH == TT * (COUT / 4), "dz tile divides over the workgroup");
-    float4 rdz[DZ_PER], ra[A_PER];
+    u32x4 rdz[DZ_PER], ra[A_PER];
+#pragma unroll
+    for (int u = 0; u < DZ_PER; ++u) rdz[u] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int u = 0; u < A_PER; ++u) ra[u] = u32x4{0u, 0u, 0u, 0u};
+    // fetch only ISSUES loads, always from rows inside the window, from one call site per tile: what lies outside the
+    // window becomes zero in stash, a tile later.  With the zeroing here (selects on the loaded values) and one fetch
+    // call per branch of "next tile of this window / first tile of the next", hipcc joined the two definitions through
+    // register copies behind an s_waitcnt vmcnt(0): every wave sat out the HBM round trip of its prefetch in front of
+    // its MFMA loop (tools/stamps_wgrad.py: 10.6 k of a tile's 32.8 k cycles).
     auto fetch = [&](int b, int t0) {
-        // dz rows t0 .. t0+TT-1 (zeros past L), all COUT channels
+        // dz rows t0 .. t0+TT-1, all COUT channels
 #pragma unroll
         for (int u = 0; u < DZ_PER; ++u) {
             const int q = threadIdx.x + u * NTH;
             const int row = q / (COUT / 4), c4 = (q % (COUT / 4)) * 4;
-            const int t = t0 + row;
-            rdz[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t < L) rdz[u] = *reinterpret_cast<const float4*>(dz + ((size_t)b * L + t) * COUT + c4);
+            const int t = min(t0 + row, L - 1);
+            g_load16(rdz[u], dz + ((size_t)b * L + t) * COUT + c4);
         }
-        // input rows t0 + j0 - pad .. (+ TT + ntap - 2), clamped = replicate padding (zero_pad: zeros outside), 32 channels
+        // input rows t0 + j0 - pad .. (+ TT + ntap - 2), clamped = replicate padding, 32 channels
+#pragma unroll
+        for (int u = 0; u < A_PER; ++u) {
+            const int q = min((int)threadIdx.x + u * NTH, A_Q - 1);
+            const int p = t0 + j0 - pad + (q >> 3);
+            const int pc = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
+            g_load16(ra[u], ain + ((size_t)b * L + pc) * CIN + ci0 + (q & 7) * 4);
+        }
+    };
+    auto landed = [&]() {  // every load of the last fetch has arrived
+#pragma unroll
+        for (int u = 0; u < DZ_PER; ++u) g_wait0(rdz[u]);
+#pragma unroll
+        for (int u = 0; u < A_PER; ++u) g_wait0(ra[u]);
+    };
+    // the tile fetched for t0: dz rows past L are zeros; zero_pad: so are the input rows outside the window
+    auto stash = [&](int t0) {
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < DZ_PER; ++u) {
+            const int q = threadIdx.x + u * NTH;
+            const int row = q / (COUT / 4);
+            *reinterpret_cast<float4*>(&s_dz[row][(q % (COUT / 4)) * 4]) = t0 + row < L ? __builtin_bit_cast(float4, rdz[u]) : zero4;
+        }
 #pragma unroll
         for (int u = 0; u < A_PER; ++u) {
             const int q = threadIdx.x + u * NTH;
             if (q < A_Q) {
                 const int p = t0 + j0 - pad + (q >> 3);
-                const int pc = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
-                ra[u] = *reinterpret_cast<const float4*>(ain + ((size_t)b * L + pc) * CIN + ci0 + (q & 7) * 4);
-                if (zero_pad && pc != p) ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(&s_a[q >> 3][(q & 7) * 4]) = (zero_pad && (p < 0 || p > L - 1)) ? zero4 : __builtin_bit_cast(float4, ra[u]);
             }
         }
     };
-    auto stash = [&]() {
-#pragma unroll
-        for (int u = 0; u < DZ_PER; ++u) {
-            const int q = threadIdx.x + u * NTH;
-            *reinterpret_cast<float4*>(&s_dz[q / (COUT / 4)][(q % (COUT / 4)) * 4]) = rdz[u];
-        }
-#pragma unroll
-        for (int u = 0; u < A_PER; ++u) {
-            const int q = threadIdx.x + u * NTH;
-            if (q < A_Q) *reinterpret_cast<float4*>(&s_a[q >> 3][(q & 7) * 4]) = ra[u];
-        }
-    };
-    if (b0 < b1) fetch(b0, 0);
-    for (int b = b0; b < b1; ++b) {
-        for (int t0 = 0; t0 < L; t0 += TT) {
-            __syncthreads();
-            stash();
-            __syncthreads();
-            if (t0 + TT < L) fetch(b, t0 + TT);
-            else if (b + 1 < b1) fetch(b + 1, 0);
-#pragma unroll 16
-            for (int s = 0; s < TT / 2; ++s) {
-                const float av = s_dz[2 * s + h][32 * wave + i];
-#pragma unroll
-                for (int j = 0; j < NTAP; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s_a[2 * s + h + j][i], acc[j], 0, 0, 0);
-            }
-        }
+#if defined(CAMAL_STAMPS) && CAMAL_STAMPS == 4
+#define WSTAMP(k) do { if (CIN == 128 && COUT == 128 && NTAP == 7 && tile == 2 && blockIdx.x == 0 && blockIdx.z < 256 && lane == 0) \
+    g_stamps[blockIdx.z][wave][k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WSTAMP(k) do {} while (0)
+#endif
+    const int tpw = (L + TT - 1) / TT, ntiles = (b1 - b0) * tpw;
+    if (ntiles > 0) {
+        fetch(b0, 0);
+        landed();  // before the loop: whatever hipcc does to join these registers with the loop's happens on landed data
     }
+    int b = b0, t0 = 0;
+    for (int tile = 0; tile < ntiles; ++tile) {
+        WSTAMP(0);
+        __syncthreads();
+        WSTAMP(1);
+        landed();
+        stash(t0);
+        WSTAMP(2);
+        __syncthreads();
+        WSTAMP(3);
+        // the next tile of this window, else the first one of the next window (after the last tile: that one again, unused)
+        int nb = b, nt0 = t0 + TT;
+        if (nt0 >= L) { nt0 = 0; ++nb; }
+        if (tile + 1 >= ntiles) { nb = b; nt0 = t0; }
+        fetch(nb, nt0);
+        WSTAMP(4);
+#pragma unroll 16
+        for (int s = 0; s < TT / 2; ++s) {
+            const float av = s_dz[2 * s + h][32 * wave + i];
+#pragma unroll
+            for (int j = 0; j < NTAP; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s_a[2 * s + h + j][i], acc[j], 0, 0, 0);
+        }
+        WSTAMP(5);
+        b = nb;
+        t0 = nt0;
+    }
+    landed();  // unconditionally: the last, unused prefetch is still in flight and nothing may reuse its registers before it lands
     // acc[j][reg]: column ci = ci0 + i, row co = 32 wave + (reg&3) + 8 (reg>>2) + 4 h
 #pragma unroll
     for (int j = 0; j < NTAP; ++j) {

@@ -62,7 +62,8 @@ def check(path):
             if t.startswith("global_load_dwordx4"):
                 pending |= regs(t.split(",")[0])
                 sb = t.split(",")[2].split()[0]
-                if not (prev.startswith("s_mov_b64") or (prev.startswith("global_load_dwordx4") and sb in prev)):
+                # a scalar base must come from the s_mov_b64 in front ("off": the address is in the lane's registers)
+                if sb != "off" and not (prev.startswith("s_mov_b64") or (prev.startswith("global_load_dwordx4") and sb in prev)):
                     findings.append((kernel, n, "asm load without s_mov_b64 in front: " + t))
             elif t.startswith("s_waitcnt vmcnt(0)"):
                 pending = set()
