@@ -413,7 +413,9 @@ def main():
     dev = f"cuda:{local_rank}"
     if not args.dry_run:
         torch.cuda.set_device(local_rank)
-    if world > 1:
+    # a launcher's environment (torch.distributed.run sets WORLD_SIZE and MASTER_*) gets its process group even for one
+    # rank: barrier and MAX then run through RCCL exactly as they do for N > 1
+    if world > 1 or ("WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ):
         import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -463,7 +465,8 @@ def main():
         line.update({"metric": head.pop("metric", "windows/sec (detect+CAM localize)"), "value": head.pop("value"),
                      "unit": head.pop("unit"), "n_gpus": world, "steps": head.pop("steps"), "warmup": head.pop("warmup"),
                      "ms_per_step": head.pop("ms_per_step"), "higher_is_better": True, "scaling": "weak",
-                     "vs_baseline": None, "dtype": head.pop("dtype"), "data": "synthetic"})
+                     "vs_baseline": None, "dtype": head.pop("dtype"), "data": "synthetic",
+                     "process_group": dist.get_backend() if dist is not None else None})
         line.update(head)
     for n in also:
         r = None

@@ -1083,12 +1083,29 @@ int camal_build_windows_static(const void* series, int series_is_f64, int n_rows
         return fail(CAMAL_ERR_ARG, "camal_build_windows_static: " + std::to_string(n_wins) + " windows exceed the static scratch's maximum of " +
                                        std::to_string(CAMAL_WINDOWS_STATIC_MAX) + " (use camal_build_windows with a caller workspace)");
     if (camal_windows_workspace_bytes(n_wins) > kWinScratchBytes) return fail(CAMAL_ERR_ARG, "static scratch too small (internal)");
+    // The scratch is per GPU: it must be the copy of the GPU that holds the caller's buffers (and runs the stream),
+    // which need not be the current device (torch tensors on cuda:1 while device 0 is current).  The device comes from
+    // the pointers themselves; the call runs with that device current and puts the caller's device back.
+    hipPointerAttribute_t pa_in, pa_out;
+    HIP_TRY(hipPointerGetAttributes(&pa_in, series));
+    HIP_TRY(hipPointerGetAttributes(&pa_out, x_out));
+    if (pa_in.type != hipMemoryTypeDevice || pa_out.type != hipMemoryTypeDevice)
+        return fail(CAMAL_ERR_ARG, "camal_build_windows_static: series_dev and x_out must be device memory");
+    if (pa_in.device != pa_out.device)
+        return fail(CAMAL_ERR_ARG, "camal_build_windows_static: series_dev and x_out live on different GPUs");
+    int prev = -1;
+    HIP_TRY(hipGetDevice(&prev));
+    const int dev = pa_out.device;
+    if (dev != prev) HIP_TRY(hipSetDevice(dev));
     void* scratch = nullptr;
-    if (int r = win_scratch_for_current_device(&scratch)) return r;
+    int r = win_scratch_for_current_device(&scratch);
     // every scratch byte a call reads (keep[0..n), pos[0..n), block totals[0..nb)) is written by that call's own
     // kernels first, so the previous call's contents need no clearing
-    return build_windows_impl(series, series_is_f64, n_rows, T, W, stride, app, stat1, stat2, x_out, x64_out, label_out,
-                              app_power_out, app_state_out, index_out, count_out, n_wins, scratch, stream);
+    if (!r)
+        r = build_windows_impl(series, series_is_f64, n_rows, T, W, stride, app, stat1, stat2, x_out, x64_out, label_out,
+                               app_power_out, app_state_out, index_out, count_out, n_wins, scratch, stream);
+    if (dev != prev) (void)hipSetDevice(prev);
+    return r;
 }
 
 static int nilm_blocks(size_t n) {

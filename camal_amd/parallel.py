@@ -82,12 +82,34 @@ def merge_member_logs(local: dict, dist=None) -> dict:
 
 
 def _active(dist=None):
-    """torch.distributed if a process group of more than one rank is up, else None."""
+    """torch.distributed if a process group of more than one rank is up, else None.
+
+    ``CAMAL_COLLECTIVES_AT_WORLD1=1`` (tests): a process group of ONE rank counts as well, so that every collective
+    of the data-parallel path (gradient all-reduce, broadcasts of rank 0's buffers / decisions / shuffle seed, the
+    per-epoch sums) really goes through the backend — RCCL on a one-GPU box — with results that must equal the
+    no-collective run bit for bit."""
     if dist is None:
         import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_available() or not dist.is_initialized():
+        return None
+    if dist.get_world_size() == 1 and os.environ.get("CAMAL_COLLECTIVES_AT_WORLD1", "0") != "1":
         return None
     return dist
+
+
+def collectives_on(dist=None) -> bool:
+    """True when the data-parallel collectives are to be issued (world > 1, or the world-1 test switch)."""
+    return _active(dist) is not None
+
+
+def control_device(d, device=None):
+    """Device of the small control-path tensors handed to a collective: the host under "gloo"; under RCCL ("nccl")
+    a GPU — ``device`` if given, else the current one (a CPU tensor has no backend there and raises)."""
+    if d.get_backend() == "gloo":
+        return torch.device("cpu")
+    if device is not None:
+        return torch.device(device)
+    return torch.device("cuda", torch.cuda.current_device())
 
 
 def rank_world(dist=None):
@@ -157,18 +179,17 @@ def broadcast_scalar(v: float, src=0, dist=None, device=None) -> float:
     d = _active(dist)
     if d is None:
         return v
-    dev = device if (device is not None and d.get_backend() != "gloo") else "cpu"
-    t = torch.tensor([float(v)], dtype=torch.float64, device=dev)
+    t = torch.tensor([float(v)], dtype=torch.float64, device=control_device(d, device))
     d.broadcast(t, src)
     return float(t.item())
 
 
-def broadcast_scalar_int(v: int, src=0, dist=None) -> int:
+def broadcast_scalar_int(v: int, src=0, dist=None, device=None) -> int:
     """Rank src's integer on every rank (the shuffle seed of an epoch)."""
     d = _active(dist)
     if d is None:
         return v
-    t = torch.tensor([int(v)], dtype=torch.int64, device="cpu" if d.get_backend() == "gloo" else torch.cuda.current_device())
+    t = torch.tensor([int(v)], dtype=torch.int64, device=control_device(d, device))
     d.broadcast(t, src)
     return int(t.item())
 
@@ -178,8 +199,7 @@ def sum_over_ranks(a: np.ndarray, dist=None, device=None) -> np.ndarray:
     d = _active(dist)
     if d is None:
         return a
-    dev = device if (device is not None and d.get_backend() != "gloo") else "cpu"
-    t = torch.as_tensor(np.asarray(a, np.float64)).to(dev)
+    t = torch.as_tensor(np.asarray(a, np.float64)).to(control_device(d, device))
     d.all_reduce(t, op=d.ReduceOp.SUM)
     return t.cpu().numpy()
 

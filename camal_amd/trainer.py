@@ -28,7 +28,13 @@ class TSLoader:
     NumPy batches.  ``shuffle=True`` consumes the global torch RNG exactly like ``DataLoader(shuffle=True)``
     does per epoch (one int64 for the iterator's base seed, one for ``RandomSampler``'s seed, then
     ``randperm`` from a fresh generator seeded with it), so the batch order under ``torch.manual_seed`` is the
-    reference's.  Under ``torch.distributed`` every rank uses rank 0's seed: the ranks cut the SAME batches."""
+    reference's.  ``sync_shuffle`` (set by a DATA-PARALLEL trainer only, never by default): every rank uses rank 0's
+    seed, so the ranks cut the SAME batches — one broadcast per shuffled pass, which every rank of the process group
+    must then make (ranks that train different members, CamAL.member_parallel, iterate their loaders a different
+    number of times and must not)."""
+
+    sync_shuffle = False
+    sync_device = None  # device of the seed tensor under RCCL (None: the current GPU)
 
     def __init__(self, X, y, batch_size=1, shuffle=False, generator=None):
         """generator: like DataLoader's — a torch.Generator the shuffles draw from instead of the global RNG (members
@@ -58,7 +64,8 @@ class TSLoader:
             order = torch.randperm(n, generator=self.generator).numpy()
         elif self.shuffle:
             seed = int(torch.empty((), dtype=torch.int64).random_().item())  # RandomSampler.__iter__
-            seed = int(parallel.broadcast_scalar_int(seed))
+            if self.sync_shuffle:
+                seed = int(parallel.broadcast_scalar_int(seed, device=self.sync_device))
             order = torch.randperm(n, generator=torch.Generator().manual_seed(seed)).numpy()
         else:
             order = np.arange(n)
@@ -171,7 +178,7 @@ class TrainEngine:
         self.sync_from_rank0()
 
     def _dp(self):
-        return self.data_parallel and parallel.rank_world()[1] > 1
+        return self.data_parallel and parallel.collectives_on()
 
     def sync_from_rank0(self):
         """Data-parallel replicas start from ONE model: rank 0's parameters, running statistics and Adam moments
@@ -325,6 +332,14 @@ def forward_train(model, x):
         eng.close()
 
 
+def configure_loader_sync(train_loader, data_parallel, device):
+    """Only a DATA-PARALLEL trainer shares rank 0's shuffle (one seed broadcast per epoch that every rank of the
+    process group must make); a trainer whose rank trains its members alone (CamAL.member_parallel) must not."""
+    if hasattr(train_loader, "sync_shuffle"):
+        train_loader.sync_shuffle = bool(data_parallel)
+        train_loader.sync_device = device
+
+
 def _is_default_ce(criterion):
     """nn.CrossEntropyLoss() as the reference constructs it: mean reduction, no class weights, no smoothing."""
     return (isinstance(criterion, torch.nn.CrossEntropyLoss) and criterion.weight is None and criterion.reduction == "mean"
@@ -350,6 +365,14 @@ class BasedClassifTrainer(object):
         length = train_loader.samples.shape[-1]
         # data_parallel is not in the reference: see CamAL.member_parallel
         self.engine = TrainEngine(self.model, self.device, train_loader.batch_size, length, data_parallel=data_parallel)
+        if all_gpu and not parallel.collectives_on() and torch.cuda.device_count() > 1:
+            # the reference's all_gpu=True wraps the model in single-process nn.DataParallel (torch_trainer.py:82-90);
+            # here data-parallel training is one process per GPU, which a single process cannot become by itself
+            warnings.warn("all_gpu=True: this process trains on one GPU.  Multi-GPU data-parallel training is one process "
+                          "per GPU: launch the same script with `python -m torch.distributed.run --nproc-per-node N ...` "
+                          "and call torch.distributed.init_process_group('nccl') first; or set CamAL.member_parallel = "
+                          "True there to train the ensemble's members on different GPUs with no gradient exchange.")
+        configure_loader_sync(train_loader, data_parallel, self.engine.device)
 
     def _init_host(self, model, train_loader, valid_loader, learning_rate, weight_decay, patience_es, patience_rlr,
                    device, all_gpu, n_warmup_epochs, f_metrics, verbose=False, plotloss=False, save_fig=False,
@@ -393,7 +416,7 @@ class BasedClassifTrainer(object):
             if self.engine._dp():
                 # every rank must take the same scheduler / early-stop / snapshot decisions (their collectives have
                 # to match): all of them act on rank 0's number
-                valid_loss = parallel.broadcast_scalar(valid_loss, 0)
+                valid_loss = parallel.broadcast_scalar(valid_loss, 0, device=self.engine.device)
 
             if self.scheduler:
                 self.lr = self.scheduler.step(valid_loss)

@@ -201,8 +201,9 @@ int camal_build_windows(const void* series_dev, int series_is_f64, int n_rows, l
  * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference: it exists only for
  * those callers.  The scratch (NaN flags, scan positions, block totals) lives in a file-scope device array of
  * camal_windows_static_scratch_bytes() = 5 MiB + 4 KiB that every GPU the library runs on holds until the process
- * ends; the call runs on the CURRENT device, makes no hipMalloc / hipFree and returns CAMAL_ERR_ARG when the series
- * yields more than CAMAL_WINDOWS_STATIC_MAX windows.  All calls on one GPU share that array: calls that overlap
+ * ends; the call runs on the GPU that holds series_dev and x_out (taken from the pointers: CAMAL_ERR_ARG when they
+ * are not device memory of ONE GPU; the caller's current device is put back), makes no hipMalloc / hipFree and
+ * returns CAMAL_ERR_ARG when the series yields more than CAMAL_WINDOWS_STATIC_MAX windows.  All calls on one GPU share that array: calls that overlap
  * on one GPU (two streams, two threads) race — serialise them.  Arguments and results as camal_build_windows. */
 #define CAMAL_WINDOWS_STATIC_MAX (1 << 20)
 size_t camal_windows_static_scratch_bytes(void);

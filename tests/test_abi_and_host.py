@@ -227,6 +227,13 @@ def test_ring_checker_sees_hazards_and_follows_out_of_line_blocks(tmp_path):
     assert len(run(load + "\ts_cbranch_vccz .LBB0_9\n.LBB0_2:\n" + mfma + tail)) == 1
     # reached after the consumer: clean
     assert run(load + mfma + "\ts_cbranch_vccz .LBB0_9\n.LBB0_2:\n" + tail) == []
+    # loop back edge: the load issued at the bottom of the body is in flight at the loop header, where a
+    # compiler-made copy of its register (a phi copy in front of the consumer) must be reported
+    loop = (".LBB0_1:\n\tv_mov_b32_e32 v30, v10\n" + mfma + load + "\ts_cbranch_scc1 .LBB0_1\n\ts_waitcnt vmcnt(0)\n\ts_endpgm\n")
+    assert len(run(load + loop)) == 1
+    assert len(run(loop)) == 1   # seen only through the back edge: nothing is in flight on the way in
+    clean_loop = (".LBB0_1:\n" + mfma + "\tv_mov_b32_e32 v30, v10\n" + load + "\ts_cbranch_scc1 .LBB0_1\n\ts_waitcnt vmcnt(0)\n\ts_endpgm\n")
+    assert run(load + clean_loop) == []
     # a load whose scalar base does not come from the s_mov_b64 in front of it
     assert len(run("\t;;#ASMSTART\n\tglobal_load_dwordx4 v[10:13], v1, s[4:5]\n\t;;#ASMEND\n" + mfma + "\ts_endpgm\n")) == 1
 
@@ -351,3 +358,101 @@ def test_trainer_epoch_logic_equals_the_references_decisions():
         stops += len(tr.loss_train_history) < sc["n_epochs"]
         drops += tr.lr < sc["lr"]
     assert stops >= 5 and drops >= 8  # the scripts do exercise early stops and LR drops
+
+
+def test_control_path_collectives_use_a_gpu_tensor_under_rccl(monkeypatch):
+    """under an RCCL process group ("nccl") every tensor handed to a collective must live on a GPU
+    (a CPU tensor raises 'No backend type associated with device type cpu').  A fake torch.distributed whose backend
+    says "nccl" + a recording control_device: the trainer's epoch loop (train), its per-epoch sums (__train) and the
+    loader's seed broadcast must all ask for the ENGINE's device, never fall back to the host."""
+    import numpy as np
+    import torch
+    from camal_amd import parallel
+    from camal_amd.trainer import BasedClassifTrainer, TSLoader
+
+    class FakeDist:
+        class ReduceOp:
+            SUM = "sum"
+
+        def __init__(self, backend):
+            self.backend, self.calls = backend, []
+
+        def is_available(self):
+            return True
+
+        def is_initialized(self):
+            return True
+
+        def get_world_size(self):
+            return 2
+
+        def get_rank(self):
+            return 0
+
+        def get_backend(self):
+            return self.backend
+
+        def broadcast(self, t, src):
+            self.calls.append(("broadcast", t.device))
+
+        def all_reduce(self, t, op=None, async_op=False):
+            self.calls.append(("all_reduce", t.device))
+
+    # the device rule itself
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 3)
+    assert parallel.control_device(FakeDist("gloo"), "cuda:1") == torch.device("cpu")
+    assert parallel.control_device(FakeDist("nccl"), "cuda:1") == torch.device("cuda:1")
+    assert parallel.control_device(FakeDist("nccl")) == torch.device("cuda", 3)
+
+    fake = FakeDist("nccl")
+    asked = []
+
+    def recording_control_device(d, device=None):
+        assert d is fake and d.get_backend() == "nccl"
+        asked.append(device)
+        return torch.device("cpu")  # no GPU here: the tensor is made on the host, what was ASKED for is the point
+
+    monkeypatch.setattr(parallel, "control_device", recording_control_device)
+    monkeypatch.setattr(parallel, "_active", lambda dist=None: fake)
+    dev = torch.device("cuda", 0)
+
+    class FakeEngine:
+        device = dev
+
+        def _dp(self):
+            return True
+
+        def store_to_model(self, model):
+            pass
+
+        def optimizer_state_dict(self, lr, wd):
+            return {}
+
+        def forward_backward(self, ts, labels, global_batch=None, loss_out=None, ncorrect_out=None):
+            pass
+
+        def optimizer_step(self, lr, wd):
+            pass
+
+    class FakeModel:
+        def state_dict(self):
+            return {}
+
+    loader = TSLoader(np.zeros((10, 4), np.float32), np.arange(10) % 2, batch_size=4, shuffle=True)
+    loader.sync_shuffle, loader.sync_device = True, dev
+    tr = BasedClassifTrainer.__new__(BasedClassifTrainer)
+    tr._init_host(FakeModel(), loader, None, 1e-3, 0, 2, 1, "cuda:0", True, 0, None)
+    tr.engine = FakeEngine()
+    real_zeros = torch.zeros
+    monkeypatch.setattr(torch, "zeros", lambda *a, **k: real_zeros(*a, **{**k, "device": "cpu"}))
+    import contextlib
+    monkeypatch.setattr(torch.cuda, "device", lambda d: contextlib.nullcontext())
+    tr.train(2)
+    kinds = [k for k, _ in fake.calls]
+    # per epoch: the shuffle seed (broadcast), the loss / accuracy sums (all_reduce), rank 0's decision value (broadcast)
+    assert kinds == ["broadcast", "all_reduce", "broadcast"] * 2, kinds
+    assert asked == [dev] * 6, asked
+    # a loader that was not told to share rank 0's shuffle issues no collective (members spread over the ranks)
+    fake.calls.clear()
+    list(TSLoader(np.zeros((10, 4), np.float32), np.arange(10) % 2, batch_size=4, shuffle=True))
+    assert fake.calls == []

@@ -94,10 +94,20 @@ def _train_worker(rank, world, port, tmp):
 
         def __init__(self, model, train_loader, valid_loader=None, **kw):
             self.k, self.data_parallel, self.log = model.kernel_size, kw["data_parallel"], {}
+            self.train_loader, self.valid_loader = train_loader, valid_loader
+            trainer_mod.configure_loader_sync(train_loader, kw["data_parallel"], None)  # as BasedClassifTrainer.__init__
 
         def train(self, epochs):
+            # the REAL loaders are walked, a different number of epochs per candidate (early stopping) and a different
+            # number of candidates per rank (3 + 2): a collective inside the loader (the shuffle-seed
+            # broadcast) would stop pairing up between the ranks and meet merge_member_logs' all_gather_object
+            self.epochs_run = {5: 1, 7: 4, 9: 2, 15: 3, 25: 5}[self.k]
+            self.batches = 0
+            for _ in range(self.epochs_run):
+                self.batches += sum(1 for _ in self.train_loader)
+                sum(1 for _ in self.valid_loader)
             self.log = {"best_model_state_dict": {"w": torch.full((3,), float(self.k))}, "trained_on_rank": rank,
-                        "data_parallel": self.data_parallel}
+                        "data_parallel": self.data_parallel, "batches": self.batches}
 
         def restore_best_weights(self):
             pass
@@ -113,13 +123,14 @@ def _train_worker(rank, world, port, tmp):
         camal = CamAL(n_predictors=3, device="cuda")
         camal.member_parallel = True
         camal.eval = lambda: None  # materialising the ensemble needs the GPU
-        camal.train((X, y), (X[:4], y[:4]), (X[4:8], y[4:8]), list_kernel_sizes=[5, 7, 9, 15, 25], epochs=1)
+        camal.train((X, y), (X[:4], y[:4]), (X[4:8], y[4:8]), list_kernel_sizes=[5, 7, 9, 15, 25], epochs=1, batch_size=16)
         logs = camal.camal_logs
         summary = {
             "ids": logs["camal_predictors_id"],
             "members": {n: [l["kernel_size"], l["trained_on_rank"], l["data_parallel"], "best_model_state_dict" in l]
                         for n, l in logs["ensemble_training_logs"].items()},
             "w9": float(logs["ensemble_training_logs"]["Predictor_2"]["best_model_state_dict"]["w"][0]),
+            "batches": [l["batches"] for l in logs["ensemble_training_logs"].values()],
         }
         with open(os.path.join(tmp, f"train{rank}.json"), "w") as f:
             json.dump(summary, f)
@@ -141,6 +152,7 @@ def test_two_rank_member_parallel_training_orchestration(tmp_path):
         assert trained_on == parallel.member_owner(i, world) and dp is False
         assert has_sd == (name in g["ids"])  # the losers' snapshots are dropped (core.py:176-179)
     assert g["w9"] == 9.0
+    assert g["batches"] == [e * 3 for e in (1, 4, 2, 3, 5)]  # 40 balanced samples, batch 16: 3 batches per epoch
 
 
 def test_member_owner_round_robin():
@@ -207,7 +219,10 @@ def _dp_worker(rank, world, port, tmp):
         assert parallel.batch_shard(1) == ((0, 1) if rank == 0 else (1, 1))
         from camal_amd.trainer import TSLoader
         torch.manual_seed(50 + rank)  # different RNG states: the order must still be rank 0's
-        order = [lab.tolist() for _, lab in TSLoader(np.zeros((9, 4)), np.arange(9), batch_size=4, shuffle=True)]
+        loader = TSLoader(np.zeros((9, 4)), np.arange(9), batch_size=4, shuffle=True)
+        assert loader.sync_shuffle is False  # opt-in: only a data-parallel trainer turns it on
+        loader.sync_shuffle = True
+        order = [lab.tolist() for _, lab in loader]
         torch.manual_seed(50)
         torch.empty((), dtype=torch.int64).random_()
         seed = int(torch.empty((), dtype=torch.int64).random_().item())

@@ -26,7 +26,12 @@ def _run(lib, _lib, torch, series, W, S, app, s1, div, static):
               _lib.ptr(out["x"]), _lib.ptr(out["x64"]), _lib.ptr(out["label"]), _lib.ptr(out["app_power"]),
               _lib.ptr(out["app_state"]), _lib.ptr(out["index"]), _lib.ptr(count))
     if static:
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info(dev)[0]
         _lib.check(lib.camal_build_windows_static(*common, stream))
+        torch.cuda.synchronize()
+        if static == "no_alloc":  # not the first call on this device (that one resolves the symbol's address)
+            assert torch.cuda.mem_get_info(dev)[0] == free0, "camal_build_windows_static changed the device's free memory"
     else:
         ws = torch.empty(int(lib.camal_windows_workspace_bytes(n)), dtype=torch.uint8, device=dev)
         _lib.check(lib.camal_build_windows(*common, _lib.ptr(ws), ws.numel(), stream))
@@ -46,7 +51,7 @@ def test_static_window_builder_equals_workspace_variant():
     small = torch.from_numpy(synth.house_series(6000, seed=4, n_app=2, nan_runs=6).astype(np.float32)).cuda()
     # two calls in a row on the static scratch, the second on a smaller input
     got_big = _run(lib, _lib, torch, big, 64, 16, 2, 0.25, 1.5, static=True)
-    got_small = _run(lib, _lib, torch, small, 100, 50, 1, 0.0, 1000.0, static=True)
+    got_small = _run(lib, _lib, torch, small, 100, 50, 1, 0.0, 1000.0, static="no_alloc")
     ref_big = _run(lib, _lib, torch, big, 64, 16, 2, 0.25, 1.5, static=False)
     ref_small = _run(lib, _lib, torch, small, 100, 50, 1, 0.0, 1000.0, static=False)
     for got, ref in ((got_big, ref_big), (got_small, ref_small)):
@@ -54,7 +59,7 @@ def test_static_window_builder_equals_workspace_variant():
         for k in ("x", "x64", "label", "app_power", "app_state", "index"):
             assert np.array_equal(got[k], ref[k]), k
     # and once more on the big input after the small one
-    again = _run(lib, _lib, torch, big, 64, 16, 2, 0.25, 1.5, static=True)
+    again = _run(lib, _lib, torch, big, 64, 16, 2, 0.25, 1.5, static="no_alloc")
     for k in ("x", "x64", "label", "app_power", "app_state", "index"):
         assert np.array_equal(again[k], ref_big[k]), k
 
@@ -77,3 +82,8 @@ def test_static_window_builder_rejects_oversize():
     assert rc == 0, lib.camal_last_error()
     torch.cuda.synchronize()
     assert int(count.item()) == 1 << 20
+    # host memory is not device memory of one GPU: refused, nothing launched
+    host = torch.zeros((1, 64), dtype=torch.float32).pin_memory()
+    rc = lib.camal_build_windows_static(_lib.ptr(host), 0, 1, 64, 8, 8, 1, 0.0, 1.0, _lib.ptr(x), None, None, None, None,
+                                        None, _lib.ptr(count), None)
+    assert rc != 0

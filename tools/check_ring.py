@@ -23,19 +23,13 @@ def regs(tok):
     return out
 
 
-def check(path):
+def _scan(lines, at_branch):
+    """One pass over a kernel's lines [(line number, text)].  at_branch[label] = registers in flight at the branches
+    known to reach `label` (grows during the pass; the caller feeds the result back in until it stops growing, so
+    that a label reached by a LATER branch — a loop's back edge — starts with that branch's loads in flight too)."""
     findings = []
-    kernel, pending, inasm, prev = None, set(), False, ""
-    # The scan follows the text; blocks the compiler moved out of line (cold paths at the end of a kernel) are
-    # entered with the loads that were in flight at the forward branches that reach them, not with whatever the
-    # text in front of them left: at_branch[label] = union over those branches, falls = the previous line falls through.
-    at_branch, falls = {}, True
-    for n, line in enumerate(open(path), 1):
-        t = line.strip()
-        if t.startswith(".amdhsa_kernel") or (t.endswith(":") and t.startswith("_Z") and "camal" in t):
-            if t.endswith(":"):
-                kernel, pending, at_branch, falls = t[:-1], set(), {}, True
-            continue
+    pending, inasm, prev, falls = set(), False, "", True
+    for n, t in lines:
         if t.startswith(".LBB") and ":" in t:
             label = t.split(":")[0]
             pending = (set(pending) if falls else set()) | at_branch.get(label, set())
@@ -64,7 +58,7 @@ def check(path):
                 sb = t.split(",")[2].split()[0]
                 # a scalar base must come from the s_mov_b64 in front ("off": the address is in the lane's registers)
                 if sb != "off" and not (prev.startswith("s_mov_b64") or (prev.startswith("global_load_dwordx4") and sb in prev)):
-                    findings.append((kernel, n, "asm load without s_mov_b64 in front: " + t))
+                    findings.append((n, "asm load without s_mov_b64 in front: " + t))
             elif t.startswith("s_waitcnt vmcnt(0)"):
                 pending = set()
             prev = t
@@ -81,9 +75,37 @@ def check(path):
             pending -= regs(ops[1])
             bad = (regs(ops[0]) | regs(ops[2]) | regs(ops[3] if len(ops) > 3 else "")) & pending
             if bad:
-                findings.append((kernel, n, "MFMA touches in-flight ring registers as non-A operand: " + t))
+                findings.append((n, "MFMA touches in-flight ring registers as non-A operand: " + t))
             continue
-        findings.append((kernel, n, "touches in-flight ring registers %s: %s" % (sorted(touched)[:4], t)))
+        findings.append((n, "touches in-flight ring registers %s: %s" % (sorted(touched)[:4], t)))
+    return findings
+
+
+def check(path):
+    # split the text into kernels
+    kernels, cur = [], None
+    for n, line in enumerate(open(path), 1):
+        t = line.strip()
+        if t.startswith(".amdhsa_kernel") or (t.endswith(":") and t.startswith("_Z") and "camal" in t):
+            if t.endswith(":"):
+                cur = (t[:-1], [])
+                kernels.append(cur)
+            continue
+        if cur is not None:
+            cur[1].append((n, t))
+    findings = []
+    for name, lines in kernels:
+        # The scan follows the text.  Blocks the compiler moved out of line (cold paths at the end of a kernel) and
+        # loop headers are entered with the loads in flight at EVERY branch that reaches them, forward or backward:
+        # iterate to a fixed point of at_branch (a copy or spill of an in-flight register that hipcc places at the top
+        # of a loop, in front of the consuming MFMA, is what the hand-placed waits cannot protect against).
+        at_branch = {}
+        for _ in range(16):
+            before = {k: set(v) for k, v in at_branch.items()}
+            found = _scan(lines, at_branch)
+            if at_branch == before:
+                break
+        findings += [(name, n, msg) for n, msg in found]
     return findings
 
 
