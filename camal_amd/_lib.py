@@ -42,6 +42,7 @@ SIGNATURES = {
     "camal_forward_cam": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "camal_forward_cam_tap": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "camal_localize": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "camal_localize_i8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _vp, _vp, _vp, _vp]),
     "camal_postprocess": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _vp, _vp, _vp, _vp, _vp]),
     "camal_attention": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "camal_windows_count": (_i, [C.c_longlong, _i, _i]),

@@ -150,7 +150,18 @@ class CamAL(object):
         # and HIP stream with its own shuffle generator (one member's short kernels fill the gaps of another's).
         # Not with data-parallel training over several ranks (their collectives must be issued in one order).
         self.member_streams = 1
+        # predict() over several GPUs from this ONE process (the reference's all_gpu idea, torch_trainer.py:82-90, for
+        # inference): ``devices`` = ["cuda:0", "cuda:1", ...], or ``all_devices = True`` for every visible GPU.  Every
+        # GPU holds all the members and takes a contiguous block of the windows on a host thread of its own; results
+        # land in disjoint slices of the output arrays; no collective.  None / False: ``device`` alone.
+        self.devices = None
+        self.all_devices = False
+        # dtypes of predict()'s arrays; the reference's are float64 (core.py:449 convolves against float64 ones).
+        # np.int8 / np.float32 keep 10 M-window runs (configs[2]) at 5 instead of 16 bytes per timestamp of host memory.
+        self.states_dtype = None
+        self.power_dtype = np.float64
         self._ensemble = None
+        self._ensembles = []
 
     # ------------------------------------------------------------------ train (core.py:47-189)
     def train(self, train_dataset: tuple, valid_dataset: tuple, test_dataset: tuple,
@@ -330,10 +341,16 @@ class CamAL(object):
         if self.list_resnet_predictors is None:
             self.eval()
 
-        # NumPy in, NumPy out (core.py:329-332): chunks through pinned buffers, copies under the kernels
-        prediction, prob, power = self._ensemble.localize_host(
-            data, y=y, w_ma=w_ma, gate_mode=int(bool(self.prefilter)), p_on=p_on, scale_mul=scale_mul,
-            scale_add=scale_add, chunk_windows=self.stream_windows)
+        # NumPy in, NumPy out (core.py:329-332): chunks through pinned buffers, copies under the kernels.
+        # The reference returns float64 states whatever the input (np.convolve against float64 ones, core.py:449)
+        sdt = self.states_dtype or np.float64
+        kw = dict(y=y, w_ma=w_ma, gate_mode=int(bool(self.prefilter)), p_on=p_on, scale_mul=scale_mul, scale_add=scale_add,
+                  chunk_windows=self.stream_windows, states_dtype=sdt, power_dtype=self.power_dtype)
+        if len(self._ensembles) > 1 and len(data) >= len(self._ensembles):
+            from .engine import localize_host_sharded
+            prediction, prob, power = localize_host_sharded(self._ensembles, data, **kw)
+        else:
+            prediction, prob, power = self._ensemble.localize_host(data, **kw)
         out = [prediction]
         if return_prob:
             out.append(prob.reshape(-1, 1))
@@ -395,9 +412,18 @@ class CamAL(object):
             sds.append(resnet_inst._params)
         self.list_resnet_predictors = list_resnet_predictors
         self.list_cam_predictors = list_cam_predictors
-        if self._ensemble is not None:
-            self._ensemble.close()
-        self._ensemble = Ensemble(sds, device=self.device, precision=self.precision)
+        for ens in self._ensembles or ([self._ensemble] if self._ensemble is not None else []):
+            ens.close()
+        devices = list(self.devices) if self.devices else None
+        if devices is None and self.all_devices:
+            devices = [f"cuda:{i}" for i in range(torch.cuda.device_count())]
+        if devices:
+            # the first entry is the instance's own device: CAM.run, test() and the mirror classes live there
+            self._ensembles = [Ensemble(sds, device=d, precision=self.precision) for d in devices]
+            self._ensemble = self._ensembles[0]
+        else:
+            self._ensemble = Ensemble(sds, device=self.device, precision=self.precision)
+            self._ensembles = [self._ensemble]
         return
 
     # -------------------------------------------- helpers kept for API parity (core.py:415-482)

@@ -626,6 +626,8 @@ int check_ctx(camal_ctx* c, int B, int L) {
 }
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+// the state output a lane writes 4 timesteps of at once: 16 bytes of float32, or 4 bytes of int8 codes
+bool state_aligned(const PostArgs& a) { return a.state8_out ? ((uintptr_t)a.state8_out & 3) == 0 : aligned16(a.state_out); }
 
 // post_stream_kernel for E members (1..8) and a 5-step moving average (the reference's default, core.py:257)
 template <bool F64>
@@ -650,7 +652,7 @@ int launch_post(camal_ctx* c, hipStream_t s, const PostArgs& a0, bool own_max) {
     static const int stream_mode = getenv("CAMAL_POST_STREAM") ? atoi(getenv("CAMAL_POST_STREAM")) : 1;
     static const int stream_blocks = getenv("CAMAL_POST_STREAM_BLOCKS") ? atoi(getenv("CAMAL_POST_STREAM_BLOCKS")) : 0;
     if (stream_mode && !own_max && a0.hdr && !a0.x64 && !a0.avg_out && a0.w_ma == 5 && a0.L % 4 == 0 && a0.E <= 8 &&
-        aligned16(a0.cam) && a0.cam_estride % 4 == 0 && aligned16(a0.x) && aligned16(a0.state_out) && aligned16(a0.power_out)) {
+        aligned16(a0.cam) && a0.cam_estride % 4 == 0 && aligned16(a0.x) && state_aligned(a0) && aligned16(a0.power_out)) {
         const int blocks = stream_blocks > 0 ? stream_blocks : (c ? c->num_cu : 256) * 16;  // measured flat from 12 to 64 per CU
         const bool ok = a0.pred_f64 ? launch_post_stream<true>(s, a0, blocks) : launch_post_stream<false>(s, a0, blocks);
         if (ok) {
@@ -661,7 +663,7 @@ int launch_post(camal_ctx* c, hipStream_t s, const PostArgs& a0, bool own_max) {
     const int tiles = (a0.L + POST_TILE - 1) / POST_TILE;
     constexpr int kMaxY = 32768;  // grid.y limit is 65535
     // 16-byte accesses when every row of every array starts on a 16-byte boundary
-    const bool vec = a0.L % 4 == 0 && aligned16(a0.cam) && a0.cam_estride % 4 == 0 && aligned16(a0.x) && aligned16(a0.state_out) &&
+    const bool vec = a0.L % 4 == 0 && aligned16(a0.cam) && a0.cam_estride % 4 == 0 && aligned16(a0.x) && state_aligned(a0) &&
                      aligned16(a0.avg_out) && aligned16(a0.power_out);
     for (int b0 = 0; b0 < a0.B; b0 += kMaxY) {
         PostArgs a = a0;
@@ -670,7 +672,9 @@ int launch_post(camal_ctx* c, hipStream_t s, const PostArgs& a0, bool own_max) {
         a.cam += o; if (a.logits) a.logits += 2 * (size_t)b0; if (a.hdr) a.hdr += (size_t)b0 * (a0.E + 1);
         a.x += o; if (a.x64) a.x64 += o; if (a.y) a.y += b0;
         if (a.prob_out) a.prob_out += b0;
-        a.state_out += o; if (a.avg_out) a.avg_out += o; if (a.power_out) a.power_out += o;
+        if (a.state_out) a.state_out += o;
+        if (a.state8_out) a.state8_out += o;
+        if (a.avg_out) a.avg_out += o; if (a.power_out) a.power_out += o;
         const dim3 grid(tiles, a.B), block(POST_THREADS);
         // 4 members per load round: 5 or 8 per round cost more registers (occupancy) than the round trip
         // they save (measured on E = 5)
@@ -893,18 +897,19 @@ int camal_postprocess(int E, const float* cam, const float* logits, const float*
     PostArgs a;
     a.cam = cam; a.logits = logits; a.hdr = nullptr; a.x = x; a.x64 = x64; a.y = y;
     a.cam_estride = (size_t)B * L; a.lg_estride = (size_t)B * 2;
-    a.prob_out = prob_out; a.avg_out = avg_cam_out; a.state_out = state_out; a.power_out = power_out;
+    a.prob_out = prob_out; a.avg_out = avg_cam_out; a.state_out = state_out; a.state8_out = nullptr; a.power_out = power_out;
     a.E = E; a.B = B; a.L = L; a.w_ma = w_ma; a.gate_mode = gate_mode; a.pred_f64 = pred_f64;
     a.p_on = p_on; a.scale_mul = scale_mul; a.scale_add = scale_add;
     return launch_post(nullptr, (hipStream_t)stream, a, true);
 }
 
-int camal_localize(camal_ctx* c, const float* x, const double* x64, const int8_t* y, int B, int L, int w_ma,
-                   int gate_mode, int pred_f64, double p_on, double scale_mul, double scale_add, double* prob_out,
-                   float* avg_cam_out, float* state_out, float* power_out, float* member_logits_out,
-                   float* member_cam_out, void* stream) {
+// camal_localize / camal_localize_i8: the states go out as float32 (state_out) or as one-byte codes (state8_out)
+static int localize_impl(camal_ctx* c, const float* x, const double* x64, const int8_t* y, int B, int L, int w_ma,
+                         int gate_mode, int pred_f64, double p_on, double scale_mul, double scale_add, double* prob_out,
+                         float* avg_cam_out, float* state_out, int8_t* state8_out, float* power_out,
+                         float* member_logits_out, float* member_cam_out, void* stream) {
     if (int r = check_ctx(c, B, L)) return r;
-    if (!x || !prob_out || !state_out) return fail(CAMAL_ERR_ARG, "x_dev, prob_out and state_out are required");
+    if (!x || !prob_out || (!state_out && !state8_out)) return fail(CAMAL_ERR_ARG, "x_dev, prob_out and state_out are required");
     if (w_ma < 1 || w_ma > 64) return fail(CAMAL_ERR_ARG, "w_ma must be in 1..64");
     if (gate_mode != 0 && gate_mode != 1) return fail(CAMAL_ERR_ARG, "gate_mode must be 0 or 1");
     hipStream_t s = (hipStream_t)stream;
@@ -956,12 +961,30 @@ int camal_localize(camal_ctx* c, const float* x, const double* x64, const int8_t
         a.x = x + (size_t)g0 * L; a.x64 = x64 ? x64 + (size_t)g0 * L : nullptr;
         a.y = nullptr;
         a.prob_out = nullptr; a.avg_out = avg_cam_out ? avg_cam_out + (size_t)g0 * L : nullptr;
-        a.state_out = state_out + (size_t)g0 * L; a.power_out = power_out ? power_out + (size_t)g0 * L : nullptr;
+        a.state_out = state_out ? state_out + (size_t)g0 * L : nullptr;
+        a.state8_out = state8_out ? state8_out + (size_t)g0 * L : nullptr;
+        a.power_out = power_out ? power_out + (size_t)g0 * L : nullptr;
         a.E = E; a.B = ng; a.L = L; a.w_ma = w_ma; a.gate_mode = gate_mode; a.pred_f64 = pred_f64;
         a.p_on = p_on; a.scale_mul = scale_mul; a.scale_add = scale_add;
         if (int r = launch_post(c, s, a, false)) return r;
     }
     return 0;
+}
+
+int camal_localize(camal_ctx* c, const float* x, const double* x64, const int8_t* y, int B, int L, int w_ma,
+                   int gate_mode, int pred_f64, double p_on, double scale_mul, double scale_add, double* prob_out,
+                   float* avg_cam_out, float* state_out, float* power_out, float* member_logits_out,
+                   float* member_cam_out, void* stream) {
+    return localize_impl(c, x, x64, y, B, L, w_ma, gate_mode, pred_f64, p_on, scale_mul, scale_add, prob_out, avg_cam_out,
+                         state_out, nullptr, power_out, member_logits_out, member_cam_out, stream);
+}
+
+int camal_localize_i8(camal_ctx* c, const float* x, const double* x64, const int8_t* y, int B, int L, int w_ma,
+                      int gate_mode, int pred_f64, double p_on, double scale_mul, double scale_add, double* prob_out,
+                      int8_t* state_out, float* power_out, void* stream) {
+    if (!state_out) return fail(CAMAL_ERR_ARG, "state_out is required");
+    return localize_impl(c, x, x64, y, B, L, w_ma, gate_mode, pred_f64, p_on, scale_mul, scale_add, prob_out, nullptr,
+                         nullptr, state_out, power_out, nullptr, nullptr, stream);
 }
 
 int camal_attention(const double* soft, const double* x, int B, int L, int w_ma, double* state_out, void* stream) {

@@ -1669,7 +1669,8 @@ struct PostArgs {
     const int8_t* y;       // [B] or null                                  (OWN_MAX only)
     double* prob_out;      // [B]                                          (OWN_MAX only)
     float* avg_out;        // [B][L] or null
-    float* state_out;      // [B][L]
+    float* state_out;      // [B][L]   (one of state_out / state8_out)
+    int8_t* state8_out;    // [B][L] or null: the states as one byte each (state_code), for callers that ship them over PCIe
     float* power_out;      // [B][L] or null
     int E, B, L, w_ma, gate_mode, pred_f64;
     double p_on, scale_mul, scale_add;
@@ -1741,6 +1742,16 @@ __device__ __forceinline__ double attention_state(double sum, int w, double inv_
     if (az >= 1e-9 && fabs(az - LN3) > 1e-6) return copysign(az > LN3 ? 1.0 : 0.0, zf);
     const double z = (sum / (double)w) * x;
     return rint(2.0 * (1.0 / (1.0 + exp(-z))) - 1.0);
+}
+
+// np.round's four possible states in one byte: 0 -> 0, 1 -> 1, -1 -> -1, -0.0 -> -128 (the sign bit alone): what
+// camal_localize_i8 writes, 1 byte per timestamp instead of 4 (include/camal_hip.h: CAMAL_STATE_NEG_ZERO)
+__device__ __forceinline__ int state_code(double st) {
+    if (st == 0.0) return signbit(st) ? -128 : 0;
+    return (int)st;
+}
+__device__ __forceinline__ unsigned pack_codes(const int (&c)[4]) {
+    return (unsigned)(c[0] & 0xff) | ((unsigned)(c[1] & 0xff) << 8) | ((unsigned)(c[2] & 0xff) << 16) | ((unsigned)(c[3] & 0xff) << 24);
 }
 
 // NS values of one window row starting at byte offset off0 (VEC: NS consecutive floats in one 16-byte load,
@@ -1948,9 +1959,11 @@ __global__ __launch_bounds__(POST_THREADS) void post_kernel(PostArgs a) {
 
     // ---- moving average, rectified sigmoid of (ma * aggregate), round, power
     float st4[POST_PER_LANE], av4[POST_PER_LANE], pw4[POST_PER_LANE];
+    int sc4[POST_PER_LANE];
 #pragma unroll
     for (int j = 0; j < POST_PER_LANE; ++j) {
         st4[j] = av4[j] = pw4[j] = 0.f;
+        sc4[j] = 0;
         if (!ok[j]) continue;
         const int i = pos[j];
         double sum = 0.0;
@@ -1959,6 +1972,7 @@ __global__ __launch_bounds__(POST_THREADS) void post_kernel(PostArgs a) {
         const double xv = a.x64 ? xd[j] : (double)xf[j];
         const double st = attention_state(sum, w, inv_w, xv);
         st4[j] = (float)st;
+        sc4[j] = state_code(st);
         av4[j] = pass ? (float)s_pred[i - lo] : 0.f;
         const double agg = xv * a.scale_mul + a.scale_add;
         double yh = (double)(int)st * a.p_on;  // astype(int) of -1, -0, 0, 1
@@ -1968,7 +1982,8 @@ __global__ __launch_bounds__(POST_THREADS) void post_kernel(PostArgs a) {
     if constexpr (VEC) {
         if (ok[0]) {
             const size_t o = row + c0 + pos[0];
-            *reinterpret_cast<float4*>(a.state_out + o) = make_float4(st4[0], st4[1], st4[2], st4[3]);
+            if (a.state8_out) *reinterpret_cast<unsigned*>(a.state8_out + o) = pack_codes(sc4);
+            else *reinterpret_cast<float4*>(a.state_out + o) = make_float4(st4[0], st4[1], st4[2], st4[3]);
             if (a.avg_out) *reinterpret_cast<float4*>(a.avg_out + o) = make_float4(av4[0], av4[1], av4[2], av4[3]);
             if (a.power_out) *reinterpret_cast<float4*>(a.power_out + o) = make_float4(pw4[0], pw4[1], pw4[2], pw4[3]);
         }
@@ -1977,7 +1992,8 @@ __global__ __launch_bounds__(POST_THREADS) void post_kernel(PostArgs a) {
         for (int j = 0; j < POST_PER_LANE; ++j) {
             if (!ok[j]) continue;
             const size_t o = row + c0 + pos[j];
-            a.state_out[o] = st4[j];
+            if (a.state8_out) a.state8_out[o] = (int8_t)sc4[j];
+            else a.state_out[o] = st4[j];
             if (a.avg_out) a.avg_out[o] = av4[j];
             if (a.power_out) a.power_out[o] = pw4[j];
         }
@@ -2054,6 +2070,7 @@ __global__ __launch_bounds__(256) void post_stream_kernel(PostArgs a, int segs_p
         }
         const float xs[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
         float st4[4], pw4[4];
+        int sc4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             double sum = 0.0;
@@ -2062,6 +2079,7 @@ __global__ __launch_bounds__(256) void post_stream_kernel(PostArgs a, int segs_p
             const double xv = (double)xs[j];
             const double st = attention_state(sum, W, inv_w, xv);
             st4[j] = (float)st;
+            sc4[j] = state_code(st);
             const double agg = xv * a.scale_mul + a.scale_add;
             double yh = (double)(int)st * a.p_on;  // astype(int) of -1, -0, 0, 1
             if (yh > agg) yh = agg;
@@ -2069,7 +2087,8 @@ __global__ __launch_bounds__(256) void post_stream_kernel(PostArgs a, int segs_p
         }
         if (owner) {
             const size_t o = row + t0;
-            *reinterpret_cast<float4*>(a.state_out + o) = make_float4(st4[0], st4[1], st4[2], st4[3]);
+            if (a.state8_out) *reinterpret_cast<unsigned*>(a.state8_out + o) = pack_codes(sc4);
+            else *reinterpret_cast<float4*>(a.state_out + o) = make_float4(st4[0], st4[1], st4[2], st4[3]);
             if (a.power_out) *reinterpret_cast<float4*>(a.power_out + o) = make_float4(pw4[0], pw4[1], pw4[2], pw4[3]);
         }
     }

@@ -98,6 +98,10 @@ class Ensemble:
             self.set_chunk_windows(chunk_windows)
 
     def close(self):
+        pipe = getattr(self, "_pipe", None)
+        if pipe is not None:
+            pipe[2].shutdown(wait=True)
+            self._pipe, self._pipe_key = None, None
         if getattr(self, "_h", None):
             self.lib.camal_destroy(self._h)
             self._h = None
@@ -185,119 +189,165 @@ class Ensemble:
             res["member_logits"], res["member_cam"] = mlog, mcam
         return res
 
+    # --- the same with the states as one-byte codes (camal_localize_i8): what the host pipeline ships over PCIe ------
+    def localize_i8(self, x, prob, state8, power=None, x64=None, y=None, w_ma=5, gate_mode=0, pred_f64=False, p_on=None,
+                    scale_mul=1.0, scale_add=0.0):
+        """``camal_localize_i8`` on device tensors the caller owns (x [B,L] float32, prob [B] float64, state8 [B,L] int8,
+        power [B,L] float32 or None): allocates nothing."""
+        B, L = x.shape
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.camal_localize_i8(
+                self._h, _lib.ptr(x), _lib.ptr(x64), _lib.ptr(y), B, L, int(w_ma), int(gate_mode), int(bool(pred_f64)),
+                float(p_on if p_on is not None else 0.0), float(scale_mul), float(scale_add),
+                _lib.ptr(prob), _lib.ptr(state8), _lib.ptr(power), self._stream()))
+
     # --- NumPy in / NumPy out for N >> what stays resident: chunks through pinned buffers, three streams ---------
+    NSETS = 3  # buffer sets of the host pipeline: one chunk computing, one on its way out, one being widened on the host
+
     def stream_chunk_windows(self, L):
         """Windows per chunk of ``localize_host`` when the caller does not say: about 6 M timesteps (4096 day
         windows, 585 week windows): a chunk's kernels run for tens of milliseconds, its copies for well under one."""
         return max(64, min(8192, (6 << 20) // max(int(L), 1)))
 
     def _host_pipeline(self, chunk, L, is64, want_power):
-        """Two sets of pinned host / device buffers for ``localize_host``, kept for the next call of the same shape
-        (pinning memory costs more than a chunk's work)."""
+        """NSETS sets of pinned host / device buffers for ``localize_host``, kept for the next call of the same shape
+        (pinning memory costs more than a chunk's work), the three streams, the worker threads that widen results into
+        the caller's arrays; the context's workspace is sized once here (camal_reserve) so that no call allocates."""
         key = (chunk, L, bool(is64), bool(want_power))
         if getattr(self, "_pipe_key", None) == key:
             return self._pipe
+        from concurrent.futures import ThreadPoolExecutor
         dev = self.device
         sets = []
         with torch.cuda.device(dev):
-            for _ in range(2):
+            for _ in range(self.NSETS):
                 b = {"in32": torch.empty((chunk, L), dtype=torch.float32).pin_memory(),
                      "d_in32": torch.empty((chunk, L), dtype=torch.float32, device=dev),
-                     "d_state": torch.empty((chunk, L), dtype=torch.float32, device=dev),
-                     "d_state64": torch.empty((chunk, L), dtype=torch.float64, device=dev),
+                     "d_state8": torch.empty((chunk, L), dtype=torch.int8, device=dev),
                      "d_prob": torch.empty((chunk,), dtype=torch.float64, device=dev),
-                     "state64": torch.empty((chunk, L), dtype=torch.float64).pin_memory(),
+                     "state8": torch.empty((chunk, L), dtype=torch.int8).pin_memory(),
                      "prob": torch.empty((chunk,), dtype=torch.float64).pin_memory(),
-                     "h2d": torch.cuda.Event(), "comp": torch.cuda.Event(), "d2h": torch.cuda.Event(), "n": 0, "s": 0}
+                     "h2d": torch.cuda.Event(), "comp": torch.cuda.Event(), "d2h": torch.cuda.Event(), "jobs": []}
                 if is64:
                     b["in64"] = torch.empty((chunk, L), dtype=torch.float64).pin_memory()
                     b["d_in64"] = torch.empty((chunk, L), dtype=torch.float64, device=dev)
                 if want_power:
                     b["d_power"] = torch.empty((chunk, L), dtype=torch.float32, device=dev)
-                    b["d_power64"] = torch.empty((chunk, L), dtype=torch.float64, device=dev)
-                    b["power64"] = torch.empty((chunk, L), dtype=torch.float64).pin_memory()
+                    b["power32"] = torch.empty((chunk, L), dtype=torch.float32).pin_memory()
                 sets.append(b)
             streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev))
-        self._pipe_key, self._pipe = key, (sets, streams)
+        self.reserve(chunk, L)
+        old = getattr(self, "_pipe", None)
+        if old is not None:
+            old[2].shutdown(wait=True)
+        pool = ThreadPoolExecutor(max_workers=self.host_workers, thread_name_prefix="camal-widen")
+        self._pipe_key, self._pipe = key, (sets, streams, pool)
         return self._pipe
 
-    def localize_host(self, data, y=None, w_ma=5, gate_mode=0, p_on=None, scale_mul=1.0, scale_add=0.0, chunk_windows=None):
+    host_workers = 4  # threads that widen a chunk's int8 states / float32 power into the caller's arrays
+
+    @staticmethod
+    def _widen_states(dst, codes):
+        """int8 state codes (0, 1, -1, -128 = -0.0: camal_localize_i8) -> the caller's array, any dtype.  float dtypes get
+        np.round's -0.0 back (core.py:437); integer dtypes have no -0: it becomes 0."""
+        np.copyto(dst, codes, casting="unsafe")
+        if codes.size and codes.min() == -128:  # only with negative (signed-scaled) inputs
+            neg = codes == -128
+            dst[neg] = -0.0 if np.issubdtype(dst.dtype, np.floating) else 0
+
+    def localize_host(self, data, y=None, w_ma=5, gate_mode=0, p_on=None, scale_mul=1.0, scale_add=0.0, chunk_windows=None,
+                      out=None, states_dtype=np.float64, power_dtype=np.float64):
         """``localize`` for host arrays of any length: ``data`` [N,L] NumPy (float32, or anything else = the float64
-        path of the reference, core.py:286) -> (states [N,L] float64, prob [N] float64, power [N,L] float64 or None)
-        as NumPy arrays.  The windows go through the device in chunks: chunk i+1's host-to-device copy and chunk
-        i-1's device-to-host copy run on their own streams under chunk i's kernels, through pinned buffers, so that
-        the device holds two chunks, not N windows (configs[2]: 10 M day windows).  Same numbers as one call of
-        ``localize`` on everything: windows are independent."""
+        path of the reference, core.py:286) -> (states [N,L], prob [N] float64, power [N,L] or None) as NumPy arrays.
+
+        The windows go through the device in chunks: chunk i+1's host-to-device copy and chunk i-1's device-to-host
+        copy run on their own streams under chunk i's kernels, through pinned buffers, so the device holds NSETS
+        chunks, not N windows (configs[2]: 10 M day windows).  What crosses PCIe is compact — float32 in, ONE byte
+        per state (camal_localize_i8) and float32 power out — and worker threads widen it into the result arrays
+        while the next chunks run.  The reference's contract is float64 states (``zeros_like(data)`` of a float64
+        array, core.py:286): that is the default; ``states_dtype`` / ``power_dtype`` (e.g. int8 / float32: 5 instead
+        of 16 bytes per timestamp of host memory) and ``out`` = {"states", "prob", "power"} arrays to fill in place
+        (np.memmap included) keep the host side bounded at that scale.  Same numbers as one call of ``localize`` on
+        everything: windows are independent."""
         data = np.asarray(data)
         N, L = data.shape
         is64 = data.dtype != np.float32
         want_power = p_on is not None
         chunk = int(chunk_windows or self.stream_chunk_windows(L))
         chunk = max(1, min(chunk, N))
-        sets, (s_h2d, s_comp, s_d2h) = self._host_pipeline(chunk, L, is64, want_power)
-        states = np.empty((N, L), dtype=np.float64)
-        prob = np.empty((N,), dtype=np.float64)
-        power = np.empty((N, L), dtype=np.float64) if want_power else None
+        sets, (s_h2d, s_comp, s_d2h), pool = self._host_pipeline(chunk, L, is64, want_power)
+        out = out or {}
+        states = out["states"] if out.get("states") is not None else np.empty((N, L), dtype=states_dtype)
+        prob = out["prob"] if out.get("prob") is not None else np.empty((N,), dtype=np.float64)
+        power = None
+        if want_power:
+            power = out["power"] if out.get("power") is not None else np.empty((N, L), dtype=power_dtype)
+        if states.shape != (N, L) or prob.shape[0] != N or (want_power and power.shape != (N, L)):
+            raise ValueError("out arrays must be states [N,L], prob [N] (or [N,1]), power [N,L]")
+        if not prob.flags.c_contiguous:
+            raise ValueError("out['prob'] must be contiguous")
+        prob_flat = prob.reshape(-1)
         if y is not None:
             y = np.asarray(y).astype(np.int8).ravel()
             if y.size != N:
                 raise ValueError("y must hold one label per window")
+        nw = max(1, int(self.host_workers))
 
-        def collect(b):  # chunk whose results sit (or will sit) in the pinned buffers of set b -> the output arrays
-            if b["n"] == 0:
-                return
+        def widen(b, s, r0, r1):  # rows [r0, r1) of the chunk at window s: pinned buffers -> the result arrays
             b["d2h"].synchronize()
-            s, n = b["s"], b["n"]
-            states[s:s + n] = b["state64"][:n].numpy()
-            prob[s:s + n] = b["prob"][:n].numpy()
+            self._widen_states(states[s + r0:s + r1], b["state8"][r0:r1].numpy())
             if want_power:
-                power[s:s + n] = b["power64"][:n].numpy()
-            b["n"] = 0
+                np.copyto(power[s + r0:s + r1], b["power32"][r0:r1].numpy(), casting="same_kind")
+            if r0 == 0:
+                n = b["n"]
+                prob_flat[s:s + n] = b["prob"][:n].numpy()
+
+        def settle(b):  # the chunk that used this set NSETS steps ago has left its pinned buffers
+            for f in b["jobs"]:
+                f.result()
+            b["jobs"] = []
 
         cur = torch.cuda.current_stream(self.device)
         for b in sets:
-            b["n"] = 0
+            settle(b)
         with torch.cuda.device(self.device):
             s_h2d.wait_stream(cur)
             s_comp.wait_stream(cur)
             for i, s in enumerate(range(0, N, chunk)):
                 n = min(chunk, N - s)
-                b = sets[i % 2]
-                collect(b)  # the chunk that used this set two steps ago: its copies have landed, buffers are free
+                b = sets[i % self.NSETS]
+                settle(b)
                 # host: stage the chunk in pinned memory (the float32 model input; the float64 original beside it)
                 b["in32"][:n].numpy()[...] = data[s:s + n]
                 if is64:
                     b["in64"][:n].numpy()[...] = data[s:s + n]
                 with torch.cuda.stream(s_h2d):
-                    s_h2d.wait_event(b["comp"])  # the kernels of chunk i-2 have read the device inputs
+                    s_h2d.wait_event(b["comp"])  # the kernels of the chunk that used this set have read the device inputs
                     b["d_in32"][:n].copy_(b["in32"][:n], non_blocking=True)
                     if is64:
                         b["d_in64"][:n].copy_(b["in64"][:n], non_blocking=True)
                     b["h2d"].record(s_h2d)
                 with torch.cuda.stream(s_comp):
                     s_comp.wait_event(b["h2d"])
-                    s_comp.wait_event(b["d2h"])  # chunk i-2's results have left the device outputs
-                    out = {"prob": b["d_prob"][:n], "state": b["d_state"][:n]}
-                    if want_power:
-                        out["power"] = b["d_power"][:n]
-                    self.localize(b["d_in32"][:n], x64=b["d_in64"][:n] if is64 else None,
-                                  y=None if y is None else y[s:s + n], w_ma=w_ma, gate_mode=gate_mode, pred_f64=is64,
-                                  p_on=p_on, scale_mul=scale_mul, scale_add=scale_add, out=out)
-                    b["d_state64"][:n].copy_(b["d_state"][:n])  # the API's float64, converted before the PCIe copy
-                    if want_power:
-                        b["d_power64"][:n].copy_(b["d_power"][:n])
+                    s_comp.wait_event(b["d2h"])  # that chunk's results have left the device outputs
+                    yd = None if y is None else torch.from_numpy(y[s:s + n]).to(self.device)
+                    self.localize_i8(b["d_in32"][:n], b["d_prob"][:n], b["d_state8"][:n],
+                                     power=b["d_power"][:n] if want_power else None, x64=b["d_in64"][:n] if is64 else None,
+                                     y=yd, w_ma=w_ma, gate_mode=gate_mode, pred_f64=is64, p_on=p_on, scale_mul=scale_mul,
+                                     scale_add=scale_add)
                     b["comp"].record(s_comp)
                 with torch.cuda.stream(s_d2h):
                     s_d2h.wait_event(b["comp"])
-                    b["state64"][:n].copy_(b["d_state64"][:n], non_blocking=True)
+                    b["state8"][:n].copy_(b["d_state8"][:n], non_blocking=True)
                     b["prob"][:n].copy_(b["d_prob"][:n], non_blocking=True)
                     if want_power:
-                        b["power64"][:n].copy_(b["d_power64"][:n], non_blocking=True)
+                        b["power32"][:n].copy_(b["d_power"][:n], non_blocking=True)
                     b["d2h"].record(s_d2h)
-                b["n"], b["s"] = n, s
-            nchunks = (N + chunk - 1) // chunk
-            for k in range(2):  # drain, oldest first
-                collect(sets[(nchunks + k) % 2])
+                b["n"] = n
+                per = -(-n // nw)
+                b["jobs"] = [pool.submit(widen, b, s, r0, min(n, r0 + per)) for r0 in range(0, n, per)]
+            for b in sets:
+                settle(b)
             cur.wait_stream(s_comp)
         return states, prob, power
 
@@ -311,3 +361,47 @@ class Ensemble:
         ms = (C.c_double * len(_lib.PROF_CLASSES))()
         _lib.check(self.lib.camal_get_profile(self._h, n, ms))
         return {name: (int(n[i]), float(ms[i])) for i, name in enumerate(_lib.PROF_CLASSES)}
+
+
+def localize_host_sharded(ensembles, data, out=None, states_dtype=np.float64, power_dtype=np.float64, **kw):
+    """``Ensemble.localize_host`` over several GPUs from ONE process (the reference's all_gpu idea for inference: a plain
+    ``python script.py`` uses every GPU): ``ensembles`` hold the same members on different devices; the windows are cut
+    into contiguous blocks (parallel.shard_bounds), one host thread per GPU runs its block through its own pinned
+    buffers and streams, and every thread writes into its own slice of the shared result arrays.  No collective, no
+    exchange.  -> (states, prob, power) as ``localize_host``."""
+    import threading
+
+    from . import parallel
+    data = np.asarray(data)
+    N, L = data.shape
+    want_power = kw.get("p_on") is not None
+    out = out or {}
+    states = out["states"] if out.get("states") is not None else np.empty((N, L), dtype=states_dtype)
+    prob = out["prob"] if out.get("prob") is not None else np.empty((N,), dtype=np.float64)
+    power = (out["power"] if out.get("power") is not None else np.empty((N, L), dtype=power_dtype)) if want_power else None
+    y = kw.pop("y", None)
+    if y is not None:
+        y = np.asarray(y).ravel()
+        if y.size != N:
+            raise ValueError("y must hold one label per window")
+    world = len(ensembles)
+    errors = [None] * world
+
+    def run(r):
+        try:
+            s, e = parallel.shard_bounds(N, world, r)
+            if e > s:
+                o = {"states": states[s:e], "prob": prob[s:e], "power": power[s:e] if want_power else None}
+                ensembles[r].localize_host(data[s:e], y=None if y is None else y[s:e], out=o, **kw)
+        except BaseException as ex:  # noqa: BLE001 — re-raised in the caller's thread
+            errors[r] = ex
+
+    threads = [threading.Thread(target=run, args=(r,), name=f"camal-gpu{r}") for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for ex in errors:
+        if ex is not None:
+            raise ex
+    return states, prob, power

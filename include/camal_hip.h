@@ -141,6 +141,17 @@ int camal_localize(camal_ctx* ctx, const float* x_dev, const double* x64_dev, co
                    double* prob_out, float* avg_cam_out, float* state_out, float* power_out,
                    float* member_logits_out, float* member_cam_out, void* stream);
 
+/* camal_localize with the states as ONE BYTE per timestamp, for callers that ship results to the host
+ * (CamAL.predict's NumPy-out contract, core.py:329-332, at configs[2]'s 10 M windows: 1 byte instead of 4 over PCIe and
+ * in the pinned staging buffers; the host widens to the caller's dtype).  np.round's four values (core.py:437) as
+ * int8: 0, 1, -1, and CAMAL_STATE_NEG_ZERO for -0.0.  Same arithmetic and the same decisions as camal_localize
+ * (one kernel, two store forms); arguments as there.                                                              */
+#define CAMAL_STATE_NEG_ZERO (-128)
+int camal_localize_i8(camal_ctx* ctx, const float* x_dev, const double* x64_dev, const int8_t* y_dev,
+                      int B, int L, int w_ma, int gate_mode, int pred_f64,
+                      double p_on, double scale_mul, double scale_add,
+                      double* prob_out, int8_t* state_out, float* power_out, void* stream);
+
 /* Post-processing only, on CAM rows / logits the caller already holds on the device
  * (same arithmetic as the tail of camal_localize).  cam_dev [E][B][L], logits_dev [E][B][2]. */
 int camal_postprocess(int n_members, const float* cam_dev, const float* logits_dev,

@@ -222,3 +222,59 @@ def test_cam_hook_on_the_second_block(precision):
         _, cam = ens.forward_cam(c["data"], cam_label=1, tap_block=1)
         assert rel_err(cam[0].cpu().numpy(), c["cams_label1"]) < 3e-2
         ens.close()
+
+
+def test_streaming_predict_compact_dtypes_and_caller_arrays():
+    """The host pipeline at configs[2]'s scale keeps the host side bounded: int8 states + float32 power (5 instead of 16
+    bytes per timestamp), written into arrays the caller brings (``out``; np.memmap works the same way).  Same
+    decisions as the one-shot resident call; -0.0 survives in float dtypes and becomes 0 in integer ones."""
+    import torch
+    from camal_amd import synth, weights
+    from camal_amd.engine import Ensemble
+    chunk, L = 48, 160
+    N = 5 * chunk + 11  # more chunks than buffer sets: every set is reused while its widening jobs are checked
+    x = (synth.ukdale_windows(N, L, seed=33) * 2.0 - 2.5).astype(np.float32)  # signed: -1 and -0 states occur
+    sds = [weights.make_state_dict(k, seed=13, head_gain=3.0) for k in (7, 15)]
+    ens = Ensemble(sds, device="cuda:0", precision="fp32")
+    ref = ens.localize(x, p_on=2000.0, scale_mul=1000.0)
+    torch.cuda.synchronize()
+    rs, rp, rw = ref["state"].cpu().numpy(), ref["prob"].cpu().numpy(), ref["power"].cpu().numpy()
+    assert (rs == -1).any() and (np.signbit(rs) & (rs == 0)).any()
+    out = {"states": np.full((N, L), 99, np.int8), "prob": np.full((N, 1), -1.0), "power": np.full((N, L), -1.0, np.float32)}
+    s8, p, w = ens.localize_host(x, p_on=2000.0, scale_mul=1000.0, chunk_windows=chunk, out=out)
+    assert s8 is out["states"] and p is out["prob"] and w is out["power"]
+    assert np.array_equal(s8, rs.astype(np.int8)) and np.array_equal(p[:, 0], rp) and np.array_equal(w, rw)
+    s32, _, w64 = ens.localize_host(x, p_on=2000.0, scale_mul=1000.0, chunk_windows=chunk, states_dtype=np.float32)
+    assert s32.dtype == np.float32 and np.array_equal(s32, rs) and np.array_equal(np.signbit(s32), np.signbit(rs))
+    assert w64.dtype == np.float64 and np.array_equal(w64, rw.astype(np.float64))
+    with pytest.raises(ValueError):
+        ens.localize_host(x, out={"states": np.empty((N, L + 1))})
+    ens.close()
+
+
+def test_predict_over_several_gpus_from_one_process():
+    """CamAL.devices: one Ensemble + host thread per GPU over contiguous window blocks, results in disjoint slices of
+    the output arrays, no collective (the reference's single-process all_gpu idea, torch_trainer.py:82-90).
+    This box has one GPU: two contexts on cuda:0 stand in for two GPUs; the result must equal the single-device
+    run bit for bit, ragged split and y gate included."""
+    from camal_amd import synth
+    c = load_case("ensemble_l256")
+    x = synth.ukdale_windows(37, c["data"].shape[1], seed=41).astype(c["data"].dtype)
+    y = (np.arange(37) % 4 != 1).astype(np.int8)
+    one = _fitted_camal(c)
+    s1, p1 = one.predict(x, return_prob=True)
+    s1y, p1y = one.predict(x, y=y, return_prob=True)
+    two = _fitted_camal(c)
+    two.devices = ["cuda:0", "cuda:0"]
+    two.stream_windows = 8
+    s2, p2 = two.predict(x, return_prob=True)
+    assert len(two._ensembles) == 2 and two._ensembles[0] is not two._ensembles[1]
+    assert s2.dtype == np.float64 and np.array_equal(s1, s2) and np.array_equal(p1, p2)
+    s2y, p2y = two.predict(x, y=y, return_prob=True)
+    assert np.array_equal(s1y, s2y) and np.array_equal(p1y, p2y)
+    assert np.array_equal(two.predict(x[:1]), s1[:1])  # fewer windows than devices: the first device alone
+    three = _fitted_camal(c)
+    three.all_devices = True  # every visible GPU (one here)
+    three.states_dtype = np.int8
+    s3 = three.predict(x)
+    assert s3.dtype == np.int8 and np.array_equal(s3, s1.astype(np.int8))
