@@ -115,7 +115,7 @@ struct camal_ctx {
     int num_cu = 256;
     size_t lds_per_cu = 160 * 1024;
     int arch = CAMAL_ARCH_CAMAL;
-    int mid = C1;  // mid_channels (camal_resnet.py:8): 64, or 32 / 128 through camal_create_widths (fp32, one kernel per ConvBlock)
+    int mid = C1;  // mid_channels (camal_resnet.py:8): 64, or 32 / 128 through camal_create_widths (one kernel per ConvBlock, fp32 or bf16)
     float* zero_row = nullptr;  // 1 KiB of zeros: what a zero-padded layer reads outside the window
     int fused = 1;  // blocks 2 and 3 as fused-block kernels (block_kernel); 0: one conv_kernel per layer
     int tap_block = 2;     // camal_forward_cam_tap: 1 = the CAM is taken from block 2's output (into tap_cam)
@@ -197,7 +197,7 @@ int make_layer(camal_ctx* c, Layer& ly, const float* w, const float* b, int cout
     const size_t packed = p.size();
     p.resize(packed + 8192, 0);  // the bf16 weight ring runs 3 groups (6 KiB) past the last out-channel tile's end
     if (int r = upload(c, &ly.wpack, p.data(), p.size())) return r;
-    if (c->precision == CAMAL_BF16 && cout == 128) {
+    if (c->precision == CAMAL_BF16 && cout == 128 && c->mid == C1) {  // block streams exist for the default widths
         p.resize(packed);
         ly.host_pack.swap(p);
     }
@@ -286,15 +286,16 @@ int fused_head_tile(size_t lds_per_cu, int k) {
 }
 
 // the per-layer CAM head is the k = 3 ConvBlock on CH = 2 mid channels: its tile configuration follows use_small_wg
-template <int CH>
+template <int CH, typename DT = float>
 int layer_head_tile(size_t lds_per_cu) {
+    if constexpr (sizeof(DT) == 2) return CH / 32 > 4 ? ConvGeom<DT, CH, CH, 4, 8>::TN : GeomW<DT, CH, CH, 4>::TN;  // as launch_conv_ex picks
     return use_small_wg<float, CH, CH, true>(lds_per_cu, 3) ? GeomW<float, CH, CH, 4>::TN : GeomW<float, CH, CH, 8>::TN;
 }
 
 // timesteps per CAM-head tile (decides the layout of the pooled partial sums)
 int head_tile_len(const camal_ctx* c, bool fused, int k) {
-    if (c->mid == 32) return layer_head_tile<64>(c->lds_per_cu);
-    if (c->mid == 128) return layer_head_tile<256>(c->lds_per_cu);
+    if (c->mid == 32) return c->precision == CAMAL_FP32 ? layer_head_tile<64>(c->lds_per_cu) : layer_head_tile<64, __bf16>(c->lds_per_cu);
+    if (c->mid == 128) return c->precision == CAMAL_FP32 ? layer_head_tile<256>(c->lds_per_cu) : layer_head_tile<256, __bf16>(c->lds_per_cu);
     if (c->precision == CAMAL_FP32)
         return fused ? fused_head_tile<float>(c->lds_per_cu, k) : layer_head_tile<C2>(c->lds_per_cu);
     return fused ? fused_head_tile<__bf16>(c->lds_per_cu, k) : GeomW<__bf16, C2, C2, 4>::TN;
@@ -407,6 +408,21 @@ int launch_conv_ex(camal_ctx* c, int num_cu, size_t lds_per_cu, int cam_row, hip
         if (use_small_wg<DT, CIN, COUT, HEAD>(lds_per_cu, ks))
             return launch_conv_w<DT, CIN, COUT, 4, RELU, HAS_RES, HEAD>(c, num_cu, lds_per_cu, cam_row, s, wpack, bias, ks, in, res,
                                                                         out, wfc, cam, part, BC, L_out, L_in, in_off, zero_row, cmax);
+    }
+    if constexpr (sizeof(DT) == 2 && COUT / 32 > 4) {
+        // bf16, 256 out-channels (mid_channels = 128): eight channel tiles = eight compute waves, 128-column tiles; large
+        // first kernels on 256 input channels take 64- or 32-column tiles (LDS)
+        auto fits = [&](auto g) { using G = decltype(g); return 2 * (size_t)G::buf_bytes(ks) + (HEAD ? G::HEAD_BYTES : 0) <= lds_per_cu; };
+        if (fits(ConvGeom<DT, CIN, COUT, 4, 8>()))
+            return launch_conv_w<DT, CIN, COUT, 8, RELU, HAS_RES, HEAD, 4>(c, num_cu, lds_per_cu, cam_row, s, wpack, bias, ks, in, res,
+                                                                           out, wfc, cam, part, BC, L_out, L_in, in_off, zero_row, cmax);
+        if constexpr (!HEAD) {
+            if (fits(ConvGeom<DT, CIN, COUT, 2, 8>()))
+                return launch_conv_w<DT, CIN, COUT, 8, RELU, HAS_RES, HEAD, 2>(c, num_cu, lds_per_cu, cam_row, s, wpack, bias, ks, in,
+                                                                               res, out, wfc, cam, part, BC, L_out, L_in, in_off, zero_row, cmax);
+            return launch_conv_w<DT, CIN, COUT, 8, RELU, HAS_RES, HEAD, 1>(c, num_cu, lds_per_cu, cam_row, s, wpack, bias, ks, in,
+                                                                           res, out, wfc, cam, part, BC, L_out, L_in, in_off, zero_row, cmax);
+        }
     }
     if constexpr (sizeof(DT) == 4) {
         using G8 = GeomW<DT, CIN, COUT, 8>;
@@ -596,8 +612,10 @@ int member_ntiles(const camal_ctx* c, const Member& m, int L) {
 int run_member_any(camal_ctx* c, hipStream_t s, const Member& m, const float* x, int BC, int L, const Workspace& w,
                    float* cam, float* part, float* logits, float* cmax) {
     int r;
-    if (c->mid == 32) r = run_member_layers<float, 32>(c, s, m, x, BC, L, w, cam, part, cmax, false);
-    else if (c->mid == 128) r = run_member_layers<float, 128>(c, s, m, x, BC, L, w, cam, part, cmax, false);
+    if (c->mid == 32) r = c->precision == CAMAL_FP32 ? run_member_layers<float, 32>(c, s, m, x, BC, L, w, cam, part, cmax, false)
+                                                      : run_member_layers<__bf16, 32>(c, s, m, x, BC, L, w, cam, part, cmax, false);
+    else if (c->mid == 128) r = c->precision == CAMAL_FP32 ? run_member_layers<float, 128>(c, s, m, x, BC, L, w, cam, part, cmax, false)
+                                                            : run_member_layers<__bf16, 128>(c, s, m, x, BC, L, w, cam, part, cmax, false);
     else r = c->precision == CAMAL_FP32 ? run_member<float>(c, s, m, x, BC, L, w, cam, part, cmax)
                                         : run_member<__bf16>(c, s, m, x, BC, L, w, cam, part, cmax);
     if (r || !logits) return r;
@@ -718,8 +736,6 @@ int camal_create_widths(int device_id, int n_members, const int* kernel_sizes, i
                         camal_ctx** out) {
     if (!out || !kernel_sizes) return fail(CAMAL_ERR_ARG, "null argument");
     if (!mid_supported(mid_channels)) return fail(CAMAL_ERR_ARG, "mid_channels must be 32, 64 or 128");
-    if (mid_channels != C1 && precision != CAMAL_FP32)
-        return fail(CAMAL_ERR_ARG, "mid_channels other than 64 run in fp32 (the bf16 kernels are built for the widths CamAL.eval instantiates)");
     if (arch != CAMAL_ARCH_CAMAL && arch != CAMAL_ARCH_RESNET) return fail(CAMAL_ERR_ARG, "arch must be 0 (CamALResNet) or 1 (ResNet)");
     if (arch == CAMAL_ARCH_RESNET)
         for (int e = 0; e < n_members; ++e)

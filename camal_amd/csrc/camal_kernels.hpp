@@ -35,6 +35,7 @@ template <> struct Elem<__bf16> { static constexpr int PER_CHUNK = 8; static con
 // the 256-byte bank row.  Rows of 128 B hold two rows per bank row, hence the shift.
 template <int CHUNKS_PER_ROW> __device__ __forceinline__ int swz(int row) {
     if (CHUNKS_PER_ROW >= 16) return row & 15;
+    if (CHUNKS_PER_ROW == 4) return (row >> 2) & 3;  // 64-byte rows (32 bf16 channels): four rows per bank row
     return (row >> 1) & 7;
 }
 
@@ -409,7 +410,7 @@ __device__ __forceinline__ void mma_layer_bf16(const char* buf, int Rb, int ks, 
     static_assert(MTW == 1, "one out-channel tile per wave");
     Frag<__bf16> (&acc)[NT] = accm[0];
     constexpr int RB = CIN * 2, NG = CIN / 32;
-    static_assert(NG == 2 || NG == 4, "64 or 128 input channels");
+    static_assert(NG == 1 || NG == 2 || NG == 4 || NG == 8, "32, 64, 128 or 256 input channels");
     constexpr int NF = 2 * NT;
     const int lane = threadIdx.x & 63;
     const unsigned loff = lane * 16;
@@ -436,6 +437,50 @@ __device__ __forceinline__ void mma_layer_bf16(const char* buf, int Rb, int ks, 
             const unsigned nxt = j + 1 < ks ? b_addr<RB>(base, R0 + j + 1, q) : cur;  // past the end: any valid address
             bf16_tap<CIN, NT, 0>(wptr, loff, cur, nxt, a, b, acc);
             cur = nxt;
+        }
+    } else if constexpr (NG == 8) {
+        // 256 input channels (mid_channels = 128): eight groups per tap, two turns of the ring; a tap's later groups sit at
+        // the first one's address XOR (group << 6) (512-byte rows: swz<> only touches the bits below)
+#pragma unroll 1
+        for (int j = 0; j < ks; ++j) {
+            const unsigned nxt = j + 1 < ks ? b_addr<RB>(base, R0 + j + 1, q) : cur;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                if (g == 0) bf16_group<RB, NT, 0>(wptr, loff, cur ^ (1u << 6), a, b, acc);
+                else if (g == 1) bf16_group<RB, NT, 1>(wptr, loff, cur ^ (2u << 6), a, b, acc);
+                else if (g == 2) bf16_group<RB, NT, 2>(wptr, loff, cur ^ (3u << 6), a, b, acc);
+                else if (g == 3) bf16_group<RB, NT, 3>(wptr, loff, cur ^ (4u << 6), a, b, acc);
+                else if (g == 4) bf16_group<RB, NT, 0>(wptr, loff, cur ^ (5u << 6), a, b, acc);
+                else if (g == 5) bf16_group<RB, NT, 1>(wptr, loff, cur ^ (6u << 6), a, b, acc);
+                else if (g == 6) bf16_group<RB, NT, 2>(wptr, loff, cur ^ (7u << 6), a, b, acc);
+                else bf16_group<RB, NT, 3>(wptr, loff, nxt, a, b, acc);
+            }
+            cur = nxt;
+        }
+    } else if constexpr (NG == 1) {
+        // 32 input channels (mid_channels = 32): one group per tap, four taps per turn of the ring, then the 1 or 3 taps
+        // an odd kernel size leaves (2 only if the caller ever passes an even one)
+        int j = 0;
+#pragma unroll 1
+        for (; j + 4 <= ks; j += 4) {
+            const unsigned a1 = b_addr<RB>(base, R0 + j + 1, q), a2 = b_addr<RB>(base, R0 + j + 2, q);
+            const unsigned a3 = b_addr<RB>(base, R0 + j + 3, q);
+            const unsigned a4 = j + 4 < ks ? b_addr<RB>(base, R0 + j + 4, q) : a3;
+            bf16_group<RB, NT, 0>(wptr, loff, a1, a, b, acc);
+            bf16_group<RB, NT, 1>(wptr, loff, a2, a, b, acc);
+            bf16_group<RB, NT, 2>(wptr, loff, a3, a, b, acc);
+            bf16_group<RB, NT, 3>(wptr, loff, a4, a, b, acc);
+            cur = a4;
+        }
+        const int rem = ks - j;  // wave-uniform
+        if (rem >= 1) {
+            const unsigned a1 = rem > 1 ? b_addr<RB>(base, R0 + j + 1, q) : cur;
+            bf16_group<RB, NT, 0>(wptr, loff, a1, a, b, acc);
+            if (rem >= 2) {
+                const unsigned a2 = rem > 2 ? b_addr<RB>(base, R0 + j + 2, q) : a1;
+                bf16_group<RB, NT, 1>(wptr, loff, a2, a, b, acc);
+                if (rem >= 3) bf16_group<RB, NT, 2>(wptr, loff, a2, a, b, acc);
+            }
         }
     } else {
         int j = 0;

@@ -70,8 +70,8 @@ size_t camal_member_blob_floats_arch(int kernel_size, int arch); /* 0 for an unk
 
 /* The same for CamALResNet(mid_channels=...) (camal_resnet.py:8,14-16: widths 1 -> mid -> 2 mid -> 2 mid; what
  * CamAL.train builds from its resnet_kwargs, core.py:36-38,106).  mid_channels 32, 64 or 128; 64 is camal_create_arch.
- * Other widths run in fp32, one kernel per ConvBlock (precision must be CAMAL_FP32).  Blob layout as above with 64 /
- * 128 replaced by mid / 2 mid.                                                                                    */
+ * Other widths run one kernel per ConvBlock, in fp32 or bf16 (the fused-block kernels are built for 64).  Blob layout
+ * as above with 64 / 128 replaced by mid / 2 mid.                                                                 */
 int camal_create_widths(int device_id, int n_members, const int* kernel_sizes, int precision, int arch, int mid_channels,
                         camal_ctx** out);
 size_t camal_member_blob_floats_widths(int kernel_size, int arch, int mid_channels); /* 0 if unsupported */

@@ -292,8 +292,49 @@ def test_other_widths_fp32_vs_reference(torch_cuda, name):
         assert rel_err(logits[e].T, c["logits"][e].T) < REL_TOL_FP32
         assert np.abs(_softmax(logits[e]) - c["probs"][e]).max() < REL_TOL_FP32
     ens.close()
-    with pytest.raises(Exception):  # the bf16 kernels exist for the default widths only
-        Ensemble(sds, device="cuda:0", precision="bf16")
+
+
+@pytest.mark.parametrize("name", golden_cases("width"))
+def test_other_widths_bf16_vs_reference(torch_cuda, name):
+    """CamALResNet(mid_channels=32 / 128) on the bf16 MFMA kernels (one per ConvBlock: 32- and 256-channel layers walk
+    one / eight K groups per tap) against the reference's fixtures, with the bf16 tolerances of the default widths."""
+    from camal_amd.engine import Ensemble
+    from tests.helpers import width_state_dicts
+    c = load_case(name)
+    sds = width_state_dicts(c)
+    ens = Ensemble(sds, device="cuda:0", precision="bf16")
+    logits, cam = ens.forward_cam(c["data"].astype(np.float32))
+    logits, cam = logits.cpu().numpy(), cam.cpu().numpy()
+    for e in range(ens.E):
+        assert rel_err(cam[e], c["cams"][e]) < 3e-2, (e, rel_err(cam[e], c["cams"][e]))
+        probs = _softmax(logits[e])
+        assert np.abs(probs - c["probs"][e]).max() < 2e-2
+        firm = np.abs(c["probs"][e][:, 1] - 0.5) > 5e-2
+        assert ((probs[:, 1] > 0.5) == (c["labels"][e] > 0))[firm].all()
+    ens.close()
+
+
+@pytest.mark.parametrize("mid,L,k", [(32, 1, 5), (32, 300, 25), (32, 1031, 9), (32, 77, 1), (32, 130, 3), (128, 70, 25), (128, 257, 7),
+                                     (128, 5, 41), (128, 600, 9)])
+def test_other_widths_bf16_localize_vs_oracle(torch_cuda, mid, L, k):
+    """ragged lengths, several tiles per window, first kernel sizes that leave every remainder of the 32-channel K loop
+    (k mod 4 = 1, 3) and the narrow tiles of large kernels on 256 channels; the ensemble body on top"""
+    from camal_amd import synth, weights
+    from camal_amd.engine import Ensemble
+    from oracle import camal_oracle as oracle
+    x = synth.ukdale_windows(5, max(L, 8), seed=500 + L)[:, :L].astype(np.float32)
+    sds = [weights.make_state_dict(kk, seed=s, mid_channels=mid, head_gain=3.0) for kk, s in ((k, 321), (7, 322))]
+    ens = Ensemble(sds, device="cuda:0", precision="bf16")
+    res = ens.localize(x, want_members=True)
+    states, prob, avg_cam, outs = oracle.camal_predict(sds, x, return_intermediate=True)
+    mcam = res["member_cam"].cpu().numpy()
+    for e in range(len(sds)):
+        assert rel_err(mcam[e], outs[e][0]) < 3e-2, (e, rel_err(mcam[e], outs[e][0]))
+    assert np.abs(res["prob"].cpu().numpy() - prob[:, 0]).max() < 2e-2
+    safe = np.abs(prob[:, 0] - 0.5) > 5e-2
+    if L >= 5 and safe.any():
+        assert (res["state"].cpu().numpy()[safe] == states[safe]).mean() >= STATE_AGREE_MIN
+    ens.close()
 
 
 @pytest.mark.parametrize("mid,L,k", [(32, 1, 5), (32, 300, 25), (32, 1031, 9), (128, 70, 25), (128, 257, 7), (128, 5, 41)])
