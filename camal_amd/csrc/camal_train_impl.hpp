@@ -397,6 +397,12 @@ int camal_trainer_set_grad_scale(camal_trainer* t, float scale) {
 namespace {
 
 // the step for mid_channels = M (widths 1 -> M -> 2M -> 2M)
+// head + loss + the whole backward pass, on the activations the forward pass left in the trainer's workspace.
+// ext_dlogits: null = mean cross-entropy on labels y; else the caller's d loss / d logits [B][2] (y may then be null)
+template <int M>
+int train_bwd_impl(camal_trainer* t, const float* params, const float* x, const int* y, const float* ext_dlogits, int B, int L,
+                   float* grads, float* logits_out, float* loss_out, int* ncorrect_out, hipStream_t s);
+
 template <int M>
 int train_fwd_bwd_impl(camal_trainer* t, const float* params, float* running, const float* x, const int* y, int B, int L,
                        float momentum, float* grads, float* logits_out, float* loss_out, int* ncorrect_out, hipStream_t s) {
@@ -440,9 +446,20 @@ int train_fwd_bwd_impl(camal_trainer* t, const float* params, float* running, co
             if (r) return r;
         }
     }
+    return train_bwd_impl<M>(t, params, x, y, nullptr, B, L, grads, logits_out, loss_out, ncorrect_out, s);
+}
+
+template <int M>
+int train_bwd_impl(camal_trainer* t, const float* params, const float* x, const int* y, const float* ext_dlogits, int B, int L,
+                   float* grads, float* logits_out, float* loss_out, int* ncorrect_out, hipStream_t s) {
+    constexpr int C1 = M, C2 = 2 * M;  // shadow the defaults
+    const TLayout& Y = t->lay;
+    const int N = B * L;
+    int r;
     // head + loss
     hipLaunchKernelGGL(head_loss_kernel<C2>, dim3(B), dim3(HEAD_LOSS_THREADS), 0, s, t->act[8], params + Y.wfc, params + Y.bfc,
-                       y ? y : (const int*)t->correct, B, L, t->grad_scale, t->pooled, t->dpool, t->logits, t->dlogits, t->loss, t->correct);
+                       y ? y : (const int*)t->correct, B, L, t->grad_scale, t->pooled, t->dpool, t->logits, t->dlogits, t->loss, t->correct,
+                       ext_dlogits);
     HIP_TRY(hipGetLastError());
     if (logits_out) HIP_TRY(hipMemcpyAsync(logits_out, t->logits, (size_t)B * 2 * 4, hipMemcpyDeviceToDevice, s));
     if (!grads) return 0;
@@ -502,6 +519,19 @@ int camal_train_fwd_bwd(camal_trainer* t, const float* params, float* running, c
     if (t->mid == 32) return train_fwd_bwd_impl<32>(t, params, running, x, y, B, L, momentum, grads, logits_out, loss_out, ncorrect_out, s);
     if (t->mid == 128) return train_fwd_bwd_impl<128>(t, params, running, x, y, B, L, momentum, grads, logits_out, loss_out, ncorrect_out, s);
     return train_fwd_bwd_impl<C1>(t, params, running, x, y, B, L, momentum, grads, logits_out, loss_out, ncorrect_out, s);
+}
+
+int camal_train_bwd_dlogits(camal_trainer* t, const float* params, const float* x, const int* y, const float* dlogits, int B,
+                            int L, float* grads, float* loss_out, int* ncorrect_out, void* stream) {
+    if (!t || !params || !x || !dlogits || !grads || !loss_out || !ncorrect_out) return fail(CAMAL_ERR_ARG, "null argument");
+    if (B < 1 || B > t->maxB || L < 1 || L > t->maxL) return fail(CAMAL_ERR_ARG, "B or L exceeds what the trainer was created for");
+    HIP_TRY(hipSetDevice(t->device));
+    hipStream_t s = (hipStream_t)stream;
+    // the data-gradient packing of this step's weights (the forward-only call packed the forward direction alone)
+    if (int r = t_pack_all(t, s, params, true)) return r;
+    if (t->mid == 32) return train_bwd_impl<32>(t, params, x, y, dlogits, B, L, grads, nullptr, loss_out, ncorrect_out, s);
+    if (t->mid == 128) return train_bwd_impl<128>(t, params, x, y, dlogits, B, L, grads, nullptr, loss_out, ncorrect_out, s);
+    return train_bwd_impl<C1>(t, params, x, y, dlogits, B, L, grads, nullptr, loss_out, ncorrect_out, s);
 }
 
 int camal_ce_eval(const float* logits, const int* labels, int B, float* loss_out, int* pred_out, void* stream) {

@@ -319,6 +319,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 // One workgroup per window: pooled = mean_t F; logits = W pooled + b; softmax; CE; argmax;
 // dlogits = grad_scale * (p - onehot) / B; dpool = W^T dlogits.  grad_scale: 1, or this rank's share b / B_global of a
 // data-parallel step's batch (every gradient of the backward pass is linear in dlogits).
+// ext_dlogits != null (camal_train_bwd_dlogits: a caller-supplied training criterion, torch_trainer.py:20,52,290): the
+// gradient of the caller's loss with respect to the logits, [B][2], used in place of the cross-entropy's.
 #define HEAD_LOSS_THREADS 1024
 template <int C>  // C = 2 mid_channels: the feature width the head sees
 __global__ __launch_bounds__(HEAD_LOSS_THREADS) void head_loss_kernel(const float* __restrict__ feat /*[B][L][C]*/,
@@ -328,7 +330,8 @@ __global__ __launch_bounds__(HEAD_LOSS_THREADS) void head_loss_kernel(const floa
                                                         float* __restrict__ dpool /*[B][C]*/,
                                                         float* __restrict__ logits /*[B][2]*/,
                                                         float* __restrict__ dlogits /*[B][2]*/,
-                                                        float* __restrict__ loss /*[B]*/, int* __restrict__ correct) {
+                                                        float* __restrict__ loss /*[B]*/, int* __restrict__ correct,
+                                                        const float* __restrict__ ext_dlogits = nullptr) {
     __shared__ float sp[HEAD_LOSS_THREADS];
     __shared__ float sl[4];
     constexpr int TG = HEAD_LOSS_THREADS / C;  // time groups per channel
@@ -363,7 +366,8 @@ __global__ __launch_bounds__(HEAD_LOSS_THREADS) void head_loss_kernel(const floa
         correct[b] = ((l1 > l0) ? 1 : 0) == y;
         logits[2 * b] = l0; logits[2 * b + 1] = l1;
         const float gs = grad_scale / (float)B;
-        const float d0 = (p0 - (y == 0 ? 1.f : 0.f)) * gs, d1 = (p1 - (y == 1 ? 1.f : 0.f)) * gs;
+        float d0 = (p0 - (y == 0 ? 1.f : 0.f)) * gs, d1 = (p1 - (y == 1 ? 1.f : 0.f)) * gs;
+        if (ext_dlogits) { d0 = ext_dlogits[2 * b] * grad_scale; d1 = ext_dlogits[2 * b + 1] * grad_scale; }
         dlogits[2 * b] = d0; dlogits[2 * b + 1] = d1;
         sl[2] = d0; sl[3] = d1;
     }

@@ -226,7 +226,8 @@ class TrainEngine:
             y = y.to(self.device).float().long().to(torch.int32).contiguous()
         return x, y
 
-    def forward_backward(self, ts, labels, update_running=True, global_batch=None, loss_out=None, ncorrect_out=None):
+    def forward_backward(self, ts, labels, update_running=True, global_batch=None, loss_out=None, ncorrect_out=None,
+                         criterion=None):
         """Train-mode forward + backward on THIS RANK's samples; fills ``self.grads``.
         -> (loss tensor[1] = this rank's mean loss, ncorrect tensor[1]).
 
@@ -234,7 +235,12 @@ class TrainEngine:
         ``len(ts) / global_batch`` of the step's batch (default: equal shares, 1 / world), so the SUM all-reduce in
         ``optimizer_step`` yields the gradient of the mean loss over the whole batch; a rank whose shard is empty
         contributes zeros.  ``loss_out`` / ``ncorrect_out``: one-element device tensors to write into instead of
-        ``self.loss`` / ``self.ncorrect`` (the trainer's per-epoch history: no host sync per batch)."""
+        ``self.loss`` / ``self.ncorrect`` (the trainer's per-epoch history: no host sync per batch).
+
+        ``criterion``: a caller-supplied training loss (torch_trainer.py:20,52,290: any callable on (logits, labels
+        as long)); None = the reference's default nn.CrossEntropyLoss(), computed in the library.  With a criterion
+        the step is forward (library) -> loss and its gradient with respect to the [b, 2] logits (torch autograd) ->
+        backward from that gradient (``camal_train_bwd_dlogits``); the loss written out is the criterion's."""
         loss_out = self.loss if loss_out is None else loss_out
         ncorrect_out = self.ncorrect if ncorrect_out is None else ncorrect_out
         n = len(ts)
@@ -251,10 +257,26 @@ class TrainEngine:
             _lib.check(self.lib.camal_trainer_set_grad_scale(self._h, float(scale)))
             self._grad_scale = scale
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.camal_train_fwd_bwd(
-                self._h, _lib.ptr(self.params), _lib.ptr(self.running) if update_running else None, _lib.ptr(x),
-                _lib.ptr(y), B, L, self.BN_MOMENTUM, _lib.ptr(self.grads), None, _lib.ptr(loss_out),
-                _lib.ptr(ncorrect_out), self._stream()))
+            if criterion is None:
+                _lib.check(self.lib.camal_train_fwd_bwd(
+                    self._h, _lib.ptr(self.params), _lib.ptr(self.running) if update_running else None, _lib.ptr(x),
+                    _lib.ptr(y), B, L, self.BN_MOMENTUM, _lib.ptr(self.grads), None, _lib.ptr(loss_out),
+                    _lib.ptr(ncorrect_out), self._stream()))
+            else:
+                logits = torch.empty((B, 2), dtype=torch.float32, device=self.device)
+                _lib.check(self.lib.camal_train_fwd_bwd(
+                    self._h, _lib.ptr(self.params), _lib.ptr(self.running) if update_running else None, _lib.ptr(x),
+                    None, B, L, self.BN_MOMENTUM, None, _lib.ptr(logits), None, None, self._stream()))
+                lg = logits.requires_grad_(True)
+                with torch.enable_grad():
+                    loss = criterion(lg.float(), y.long())  # torch_trainer.py:290
+                dlog, = torch.autograd.grad(loss, lg)
+                dlog = dlog.contiguous().float()
+                ce = torch.empty(1, dtype=torch.float32, device=self.device)
+                _lib.check(self.lib.camal_train_bwd_dlogits(
+                    self._h, _lib.ptr(self.params), _lib.ptr(x), _lib.ptr(y), _lib.ptr(dlog), B, L, _lib.ptr(self.grads),
+                    _lib.ptr(ce), _lib.ptr(ncorrect_out), self._stream()))
+                loss_out.copy_(loss.detach().reshape(1))
         if update_running:
             self.num_batches_tracked += 1
         return loss_out, ncorrect_out
@@ -352,11 +374,14 @@ class BasedClassifTrainer(object):
                  valid_criterion=None, n_warmup_epochs=0, f_metrics=Classifmetrics(), verbose=False,
                  plotloss=False, save_fig=False, path_fig=None, save_checkpoint=False, path_checkpoint=None,
                  data_parallel=True):
-        if criterion is not None and not _is_default_ce(criterion):
-            raise NotImplementedError("the HIP training step implements nn.CrossEntropyLoss() with default arguments "
-                                      "(the reference's default criterion, torch_trainer.py:20)")
-        # valid_criterion (torch_trainer.py:23,53-56): None or the default cross-entropy -> the HIP evaluation kernel;
-        # anything else is applied to the eval-mode logits batch by batch, in torch
+        # criterion (torch_trainer.py:20,52): None or the default nn.CrossEntropyLoss() -> loss and its gradient in the
+        # library; anything else is evaluated by torch on the [b, 2] logits of every batch, and the library runs the
+        # backward pass from its gradient (camal_train_bwd_dlogits)
+        self.train_criterion = None if criterion is None or _is_default_ce(criterion) else criterion
+        # valid_criterion (torch_trainer.py:23,53-56: the training criterion unless given): the default cross-entropy
+        # -> the HIP evaluation kernel; anything else is applied to the eval-mode logits batch by batch, in torch
+        if valid_criterion is None:
+            valid_criterion = criterion
         self.valid_criterion = None if valid_criterion is None or _is_default_ce(valid_criterion) else valid_criterion
         self._init_host(model, train_loader, valid_loader, learning_rate, weight_decay, patience_es, patience_rlr, device,
                         all_gpu, n_warmup_epochs, f_metrics, verbose, plotloss, save_fig, path_fig, save_checkpoint,
@@ -508,7 +533,7 @@ class BasedClassifTrainer(object):
             n = len(labels)
             lo, hi = parallel.batch_shard(n) if eng._dp() else (0, n)
             eng.forward_backward(ts[lo:hi], labels[lo:hi], global_batch=n, loss_out=loss_hist[i:i + 1],
-                                 ncorrect_out=nc_hist[i:i + 1])
+                                 ncorrect_out=nc_hist[i:i + 1], criterion=getattr(self, "train_criterion", None))
             eng.optimizer_step(self.lr, self.weight_decay)
             share[i] = (hi - lo) / n
             total += n

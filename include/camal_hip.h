@@ -274,6 +274,21 @@ int camal_train_fwd_bwd(camal_trainer* t, const float* params_dev, float* bn_run
                         float* grads_dev, float* logits_dev, float* loss_dev, int* ncorrect_dev,
                         void* stream);
 
+/* Backward pass for a caller-supplied training criterion (BasedClassifTrainer's `criterion` argument,
+ * torch_trainer.py:20,52,290-291: any callable on (logits, labels)).  Protocol for one batch:
+ *   1. camal_train_fwd_bwd(t, params, running, x, NULL, B, L, momentum, NULL (= grads), logits_dev, NULL, NULL, stream)
+ *      = the train-mode forward; the activations stay in the trainer's workspace;
+ *   2. the caller evaluates its loss on logits_dev and differentiates it with respect to them (torch autograd on a
+ *      [B][2] tensor) -> dlogits_dev [B][2] float32;
+ *   3. camal_train_bwd_dlogits: the head's and every layer's gradients from dlogits_dev (x the grad scale), written to
+ *      grads_dev exactly as camal_train_fwd_bwd writes them for the cross-entropy.
+ * y_dev: labels for the accuracy count (NULL: ncorrect is meaningless); loss_dev receives the batch's mean
+ * cross-entropy when y_dev is given (the caller's own loss value is the caller's).  No other call on this trainer
+ * may come between steps 1 and 3.                                                                                */
+int camal_train_bwd_dlogits(camal_trainer* t, const float* params_dev, const float* x_dev, const int* y_dev,
+                            const float* dlogits_dev, int B, int L, float* grads_dev, float* loss_dev, int* ncorrect_dev,
+                            void* stream);
+
 /* Evaluation loss of BasedClassifTrainer.evaluate / __evaluate (torch_trainer.py:188-193,316-321) from eval-mode
  * logits (camal_forward_cam): per-window cross-entropy (float32, -log_softmax[label]) and predicted label (argmax,
  * the first maximum like torch.max).  logits_dev [B][2] float32, labels_dev [B] int32, loss_out [B] float32,

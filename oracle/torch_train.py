@@ -66,12 +66,13 @@ class FunctionalResNet:
         return out
 
 
-def loss_and_grads(sd, x, y):
-    """One train-mode forward/backward -> (loss, ncorrect, {key: grad}, updated state dict)."""
+def loss_and_grads(sd, x, y, criterion=None):
+    """One train-mode forward/backward -> (loss, ncorrect, {key: grad}, updated state dict).  criterion: the trainer's
+    `criterion` argument (torch_trainer.py:20,290); None = nn.CrossEntropyLoss()."""
     m = FunctionalResNet(sd)
     logits = m.forward(torch.as_tensor(np.asarray(x, np.float32)))
     labels = torch.as_tensor(np.asarray(y)).float().long()
-    loss = F.cross_entropy(logits.float(), labels)
+    loss = F.cross_entropy(logits.float(), labels) if criterion is None else criterion(logits.float(), labels)
     loss.backward()
     m.nbt += 1
     grads = {k: m.p[k].grad.numpy().copy() for k in m.keys}

@@ -247,8 +247,9 @@ def test_camal_train_members_side_by_side():
 
 def test_criterion_arguments_and_reserved_workspace():
     """criterion / valid_criterion of the reference's constructor (torch_trainer.py:20,23,52-56): the default
-    cross-entropy object is accepted, another training criterion is refused, a caller's validation criterion is
-    applied to the eval-mode logits; evaluation losses equal torch's cross-entropy on the same logits."""
+    cross-entropy object is accepted (and runs in the library), another training criterion is taken as it is
+    (test_custom_training_criterion_vs_oracle) and becomes the validation criterion too, a caller's validation criterion
+    is applied to the eval-mode logits; evaluation losses equal torch's cross-entropy on the same logits."""
     import torch
     from camal_amd import synth
     from camal_amd.resnet import CamALResNet
@@ -257,9 +258,12 @@ def test_criterion_arguments_and_reserved_workspace():
     torch.manual_seed(3)
     m = CamALResNet(kernel_size=5)
     tl, vl = TSLoader(x[:32], y[:32], batch_size=16), TSLoader(x[32:], y[32:], batch_size=1)
-    with pytest.raises(NotImplementedError):
-        BasedClassifTrainer(m, tl, criterion=torch.nn.CrossEntropyLoss(label_smoothing=0.1), device="cuda:0")
+    smooth = torch.nn.CrossEntropyLoss(label_smoothing=0.1)
+    tr0 = BasedClassifTrainer(m, tl, criterion=smooth, device="cuda:0")
+    assert tr0.train_criterion is smooth and tr0.valid_criterion is smooth
+    tr0.engine.close()
     tr = BasedClassifTrainer(m, tl, valid_loader=vl, criterion=torch.nn.CrossEntropyLoss(), device="cuda:0", weight_decay=0)
+    assert tr.train_criterion is None and tr.valid_criterion is None  # the library's own cross-entropy
     tr.train(1)
     loss, metrics = tr.evaluate(vl)
     m.eval()
@@ -303,3 +307,49 @@ def test_reserve_keeps_the_call_path_free_of_allocations():
         a.reserve(0, 10)
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("k,B,L", [(7, 12, 96), (25, 9, 70)])
+def test_custom_training_criterion_vs_oracle(k, B, L):
+    """BasedClassifTrainer(criterion=...) (torch_trainer.py:20,52,290): a criterion other than the default
+    cross-entropy — class weights + label smoothing — is evaluated by torch on the [B, 2] logits and the library runs
+    the backward pass from its gradient (camal_train_bwd_dlogits): loss, every gradient tensor and the running
+    statistics against torch autograd through the whole model; then two epochs through the trainer."""
+    import torch
+    from camal_amd import synth
+    from camal_amd.trainer import BasedClassifTrainer, TSLoader
+    from oracle import torch_train
+    from tests.helpers import model_for
+    x, y = synth.ideal_windows(B, L, seed=6)
+    sd0 = weights.make_state_dict(k, seed=32, head_gain=1.0)
+    w = torch.tensor([0.3, 1.7])
+    loss_ref, nc_ref, g_ref, sd1 = torch_train.loss_and_grads(sd0, x, y, criterion=torch.nn.CrossEntropyLoss(weight=w, label_smoothing=0.1))
+    crit = torch.nn.CrossEntropyLoss(weight=w.cuda(), label_smoothing=0.1)
+    m, eng = _engine(sd0, k, B, L)
+    loss, ncorrect = eng.forward_backward(x, y, criterion=crit)
+    assert abs(loss.item() - loss_ref) < 1e-4 and int(ncorrect.item()) == nc_ref
+    grads = _grads_dict(eng, m)
+    gmax = max(np.abs(g).max() for g in g_ref.values())
+    checked = 0
+    for kk in eng.keys:
+        if is_bn_fed_bias(kk) or np.abs(g_ref[kk]).max() < 1e-5 * gmax:
+            assert np.abs(grads[kk]).max() < 1e-4 * gmax, kk
+            continue
+        err = np.abs(grads[kk] - g_ref[kk]).max() / np.abs(g_ref[kk]).max()
+        assert err < 1e-3, (kk, err)
+        checked += 1
+    assert checked >= len(eng.keys) - 13
+    eng.store_to_model(m)
+    for kk in ("layers.2.layers.2.layers.1.running_mean", "layers.0.residual.1.running_var"):
+        assert np.allclose(m._params[kk], sd1[kk], rtol=1e-4, atol=1e-6)
+    eng.close()
+    # the same criterion through the trainer: it is the validation criterion too unless one is given (:52-56)
+    m2 = model_for(sd0)
+    m2.to("cuda:0")
+    m2.load_state_dict(sd0)
+    tr = BasedClassifTrainer(m2, TSLoader(x, y, batch_size=5, shuffle=True), valid_loader=TSLoader(x[:4], y[:4], batch_size=1),
+                             criterion=crit, device="cuda:0", weight_decay=0)
+    assert tr.train_criterion is crit and tr.valid_criterion is crit
+    tr.train(2)
+    assert len(tr.loss_train_history) == 2 and np.isfinite(tr.loss_train_history).all() and np.isfinite(tr.loss_valid_history).all()
+    tr.engine.close()
