@@ -337,7 +337,49 @@ def run_train(name, wl, steps, warmup, R, args, min_seconds=0.0):
         e.close()
     del engines
     torch.cuda.empty_cache()
+    if res is not None and R.world == 1 and not args.no_extras:
+        res["host_to_host"] = train_host_to_host(wl, dev)
     return res
+
+
+def train_host_to_host(wl, dev, k=7, n_batches=48):
+    """End to end as CamAL.train's callers see it, for ONE member (the reference trains them one after the other,
+    core.py:104-158): NumPy windows and labels in host memory -> BasedClassifTrainer.train(1), i.e. an epoch of
+    shuffled batches with forward + backward + AdamW, the epoch's loss / accuracy read back, the best-state snapshot.
+    Beside it the same member's step on HBM-resident tensors.  Not `value`."""
+    import numpy as np
+    import torch
+    from camal_amd import synth
+    from camal_amd.resnet import CamALResNet
+    from camal_amd.trainer import BasedClassifTrainer, TrainEngine, TSLoader
+    B, L = wl["B"], wl["L"]
+    x, y = synth.ideal_windows(B * n_batches, L, seed=77)
+    torch.manual_seed(k)
+    tr = BasedClassifTrainer(CamALResNet(kernel_size=k), TSLoader(x, y, batch_size=B, shuffle=True), device=dev,
+                             learning_rate=1e-3, weight_decay=0)
+    tr.train(1)  # warm-up epoch: the training set moves into HBM here
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tr.train(2)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 2
+    eng = tr.engine
+    xd, yd = torch.from_numpy(x[:B]).to(dev), torch.from_numpy(y[:B]).to(dev)
+    for _ in range(5):
+        eng.forward_backward(xd, yd)
+        eng.optimizer_step(1e-3, 0.0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_batches):
+        eng.forward_backward(xd, yd)
+        eng.optimizer_step(1e-3, 0.0)
+    torch.cuda.synchronize()
+    dr = time.perf_counter() - t0
+    eng.close()
+    return {"value": B * n_batches / dt, "unit": "windows/s", "member_kernel_size": k, "windows_per_epoch": B * n_batches,
+            "seconds_per_epoch": dt, "resident_step_windows_per_s": B * n_batches / dr, "frac_of_resident": dr / dt,
+            "what": "BasedClassifTrainer.train on NumPy arrays (one member, no validation loader): epoch wall clock incl. "
+                    "shuffle, per-epoch read-back and state snapshot, against the same steps on resident tensors"}
 
 
 def cpu_baseline(gpu_sds=None, gpu_x=None):

@@ -57,7 +57,8 @@ class TSLoader:
         validation passes included)."""
         torch.empty((), dtype=torch.int64).random_(generator=getattr(self, "generator", None))
 
-    def __iter__(self):
+    def epoch_order(self):
+        """The sample order of one pass, drawing from the RNG exactly what ``DataLoader``'s iterator would."""
         n = len(self.samples)
         self.draw_base_seed()
         if self.shuffle and self.generator is not None:  # RandomSampler with a generator permutes from it directly
@@ -69,6 +70,11 @@ class TSLoader:
             order = torch.randperm(n, generator=torch.Generator().manual_seed(seed)).numpy()
         else:
             order = np.arange(n)
+        return order
+
+    def __iter__(self):
+        n = len(self.samples)
+        order = self.epoch_order()
         for s in range(0, n, self.batch_size):
             idx = order[s:s + self.batch_size]
             yield self.samples[idx], self.labels[idx]
@@ -223,7 +229,9 @@ class TrainEngine:
         y = None
         if labels is not None:
             y = labels if torch.is_tensor(labels) else torch.as_tensor(np.asarray(labels))
-            y = y.to(self.device).float().long().to(torch.int32).contiguous()
+            if not (y.dtype == torch.int32 and y.is_cuda):  # labels.float() ... .long() of torch_trainer.py:285,290
+                y = y.to(self.device).float().long().to(torch.int32)
+            y = y.contiguous()
         return x, y
 
     def forward_backward(self, ts, labels, update_running=True, global_batch=None, loss_out=None, ncorrect_out=None,
@@ -290,6 +298,27 @@ class TrainEngine:
             _lib.check(self.lib.camal_train_fwd_bwd(self._h, _lib.ptr(self.params), None, _lib.ptr(x), None, B, L,
                                                     self.BN_MOMENTUM, None, _lib.ptr(logits), None, None, self._stream()))
         return logits
+
+    # ---- the training set resident in HBM ------------------------------------------------------------
+    RESIDENT_FRACTION = 0.25  # of the GPU's free memory a training set may take to stay resident
+
+    def make_resident(self, loader):
+        """Copy a TSLoader's windows and labels to the GPU once (pinned staging, one asynchronous copy) if they fit in a
+        quarter of the free HBM (288 GB per MI355X: every set the reference's data builders produce does): an epoch then
+        moves a permutation to the device instead of one synchronous pageable copy per batch (torch_trainer.py:284-285).
+        -> (X [n, L] float32, y [n] int32) device tensors, or None."""
+        X = loader.samples[:, 0, :] if loader.samples.ndim == 3 else loader.samples
+        need = X.size * 4 + loader.labels.size * 4
+        with torch.cuda.device(self.device):
+            if need > self.RESIDENT_FRACTION * torch.cuda.mem_get_info(self.device)[0]:
+                return None
+            hx = torch.empty(X.shape, dtype=torch.float32).pin_memory()
+            hx.numpy()[...] = X
+            hy = torch.from_numpy(np.asarray(loader.labels, dtype=np.float32).astype(np.int32)).pin_memory()
+            xd = hx.to(self.device, non_blocking=True)
+            yd = hy.to(self.device, non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()  # the pinned staging buffers go away with this frame
+        return xd, yd
 
     def start_grad_allreduce(self):
         """Begin this member's gradient all-reduce and return at once; hand the result to ``optimizer_step(...,
@@ -529,20 +558,48 @@ class BasedClassifTrainer(object):
             nc_hist = torch.zeros(n_batches, dtype=torch.int32, device=eng.device)
         share = np.zeros(n_batches)
         total = 0
-        for i, (ts, labels) in enumerate(self.train_loader):
-            n = len(labels)
-            lo, hi = parallel.batch_shard(n) if eng._dp() else (0, n)
-            eng.forward_backward(ts[lo:hi], labels[lo:hi], global_batch=n, loss_out=loss_hist[i:i + 1],
-                                 ncorrect_out=nc_hist[i:i + 1], criterion=getattr(self, "train_criterion", None))
-            eng.optimizer_step(self.lr, self.weight_decay)
-            share[i] = (hi - lo) / n
-            total += n
+        crit = getattr(self, "train_criterion", None)
+        res = self._resident_train_set()
+        if res is not None:
+            # the windows wait in HBM: one permutation per epoch goes to the device, batches are gathered there
+            xd, yd = res
+            order = self.train_loader.epoch_order()
+            bs = self.train_loader.batch_size
+            with torch.cuda.device(eng.device):
+                idx = torch.from_numpy(np.ascontiguousarray(order, dtype=np.int64)).to(eng.device)
+                for i, s in enumerate(range(0, len(order), bs)):
+                    n = min(bs, len(order) - s)
+                    lo, hi = parallel.batch_shard(n) if eng._dp() else (0, n)
+                    sel = idx[s + lo:s + hi]
+                    eng.forward_backward(xd.index_select(0, sel), yd.index_select(0, sel), global_batch=n,
+                                         loss_out=loss_hist[i:i + 1], ncorrect_out=nc_hist[i:i + 1], criterion=crit)
+                    eng.optimizer_step(self.lr, self.weight_decay)
+                    share[i] = (hi - lo) / n
+                    total += n
+        else:
+            for i, (ts, labels) in enumerate(self.train_loader):
+                n = len(labels)
+                lo, hi = parallel.batch_shard(n) if eng._dp() else (0, n)
+                eng.forward_backward(ts[lo:hi], labels[lo:hi], global_batch=n, loss_out=loss_hist[i:i + 1],
+                                     ncorrect_out=nc_hist[i:i + 1], criterion=crit)
+                eng.optimizer_step(self.lr, self.weight_decay)
+                share[i] = (hi - lo) / n
+                total += n
         losses = loss_hist.cpu().numpy().astype(np.float64) * share  # this rank's part of each batch's mean loss
         corrects = nc_hist.cpu().numpy().astype(np.float64)
         if eng._dp():
             both = parallel.sum_over_ranks(np.concatenate([losses, corrects]), device=eng.device)
             losses, corrects = both[:n_batches], both[n_batches:]
         return np.mean(losses), np.sum(corrects) / total
+
+    def _resident_train_set(self):
+        """The training windows on the GPU (TrainEngine.make_resident), made on first use; None for loaders that are not
+        TSLoaders (any iterable of (ts, labels) batches works, one host-to-device copy per batch like the reference)."""
+        if not hasattr(self, "_resident"):
+            tl = self.train_loader
+            ok = isinstance(tl, TSLoader) and hasattr(self.engine, "make_resident") and getattr(self, "resident", True)
+            self._resident = self.engine.make_resident(tl) if ok else None
+        return self._resident
 
     def __evaluate(self):
         losses, y, y_hat = self._eval_loader(self.valid_loader)

@@ -353,3 +353,29 @@ def test_custom_training_criterion_vs_oracle(k, B, L):
     tr.train(2)
     assert len(tr.loss_train_history) == 2 and np.isfinite(tr.loss_train_history).all() and np.isfinite(tr.loss_valid_history).all()
     tr.engine.close()
+
+
+def test_resident_training_set_equals_per_batch_copies():
+    """The trainer keeps a TSLoader's windows in HBM and gathers every batch there from the epoch's permutation
+    (TrainEngine.make_resident); `resident = False` copies batch by batch from the host like the reference
+    (torch_trainer.py:284-285).  Same shuffles, same numbers, bit for bit."""
+    import torch
+    from camal_amd import synth
+    from camal_amd.resnet import CamALResNet
+    from camal_amd.trainer import BasedClassifTrainer, TSLoader
+    x, y = synth.ideal_windows(50, 72, seed=12)
+
+    def run(resident):
+        torch.manual_seed(21)
+        m = CamALResNet(kernel_size=9)
+        tr = BasedClassifTrainer(m, TSLoader(x[:44], y[:44], batch_size=16, shuffle=True),
+                                 valid_loader=TSLoader(x[44:], y[44:], batch_size=1), device="cuda:0", weight_decay=0)
+        tr.resident = resident
+        tr.train(3)
+        assert (tr._resident is not None) == resident
+        tr.engine.close()
+        return tr.loss_train_history, tr.loss_valid_history, {k: v.numpy() for k, v in m.state_dict().items()}
+
+    a, b = run(True), run(False)
+    assert a[0] == b[0] and a[1] == b[1]
+    assert all(np.array_equal(a[2][k], b[2][k]) for k in a[2])
