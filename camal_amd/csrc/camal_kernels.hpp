@@ -636,6 +636,23 @@ __device__ unsigned long long g_stamps[256][9][CAMAL_NSTAMP];
 #define CSTAMP(i) do {} while (0)
 #endif
 
+// Tile order of conv_kernel's persistent loop.  A window's last tile is short when L is just past a multiple of the tile
+// width (the data gradient's L + 2 pad = 516 rows: eight 64-row tiles + 4 rows); in plain (window, tile) order those
+// cheap tiles are spread through the rounds and the last, partly filled round still consists of full tiles.  With a short
+// tail the full tiles of all windows come first and the short ones last: 1152 tiles on 512 workgroups take 2 + a short
+// round instead of 3.  Wave-uniform arithmetic, the same in the loader and the compute waves.
+__device__ __forceinline__ void conv_tile_coords(int tile, int tpw, int total_tiles, int L, int TN, int& b, int& tx) {
+    const int rem = L - (tpw - 1) * TN;  // rows of a window's last tile
+    if (tpw > 1 && 2 * rem <= TN) {
+        const int nb = total_tiles / tpw, full = nb * (tpw - 1);
+        if (tile < full) { b = tile / (tpw - 1); tx = tile - b * (tpw - 1); }
+        else { b = tile - full; tx = tpw - 1; }
+    } else {
+        b = tile / tpw;
+        tx = tile - b * tpw;
+    }
+}
+
 template <typename DT, int CIN, int COUT, int NT, int NWC>
 struct ConvGeom {
     static constexpr int ES = sizeof(DT);
@@ -683,7 +700,9 @@ __global__ __launch_bounds__((NWC + 1) * 64) void conv_kernel(const DT* __restri
         // ------------------------------ loader wave ------------------------------------
         const int pieces = bufb >> 10;
         auto stage = [&](int tile, char* buf) {
-            const int b = tile / tiles_per_window, t0 = (tile - b * tiles_per_window) * TN;
+            int b, tx;
+            conv_tile_coords(tile, tiles_per_window, total_tiles, L, TN, b, tx);
+            const int t0 = tx * TN;
             const char* inb = reinterpret_cast<const char*>(in + (size_t)b * L_in * CIN);
             for (int pc = 0; pc < pieces; ++pc) {
                 const int q = pc * 64 + lane;
@@ -724,7 +743,9 @@ __global__ __launch_bounds__((NWC + 1) * 64) void conv_kernel(const DT* __restri
     int it = 0;
     for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x, ++it) {
         const char* buf = lds + (it & 1) * bufb;
-        const int b = tile / tiles_per_window, tx = tile - b * tiles_per_window, t0 = tx * TN;
+        int b, tx;
+        conv_tile_coords(tile, tiles_per_window, total_tiles, L, TN, b, tx);
+        const int t0 = tx * TN;
 
         F accw[1][NT];
         F (&acc)[NT] = accw[0];
@@ -732,7 +753,16 @@ __global__ __launch_bounds__((NWC + 1) * 64) void conv_kernel(const DT* __restri
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt].zero();
 
-        mma_layer<DT, CIN, NT, 1>(buf, Rb, ks, wp, accw);
+        // A window's last tile is often nearly empty (the data gradient's extended range L + 2 pad = 516 rows is eight
+        // 64-row tiles + 4 rows): a wave whose columns all lie past the end skips its K loop, one that needs only its
+        // first 32-column tile runs the K loop on that tile alone (fp32, two column tiles per wave).  Wave-uniform.
+        const int cols_left = L - t0 - Rb;  // of this wave's NT * 32 columns, how many exist
+        if constexpr (sizeof(DT) == 4 && NT == 2 && !HEAD) {
+            if (cols_left > 32) mma_layer<DT, CIN, NT, 1>(buf, Rb, ks, wp, accw);
+            else if (cols_left > 0) mma_layer<DT, CIN, 1, 1>(buf, Rb, ks, wp, reinterpret_cast<F (&)[1][1]>(accw));
+        } else {
+            mma_layer<DT, CIN, NT, 1>(buf, Rb, ks, wp, accw);
+        }
         CSTAMP(1);
 
         // ---- epilogue.  acc[nt] group g: column t0 + Rb + 32 nt + col(g), channels 32 mt + chan(g) + 0..3
