@@ -384,7 +384,8 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restric
     for (int idx = threadIdx.x; idx < 2 * C; idx += 256) {  // C = 128: one element per thread, as before
         const int k = idx / C, c = idx - k * C;
         float a = 0.f;
-#pragma unroll 8
+        // 32 windows' loads in flight per lane (the sum keeps its order): 8 at a time was 16 dependent round trips, 33 us
+#pragma unroll 32
         for (int b = 0; b < B; ++b) a = fmaf(dlogits[2 * b + k], pooled[(size_t)b * C + c], a);
         dwfc[k * C + c] = a;
     }
