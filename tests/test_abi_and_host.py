@@ -428,7 +428,7 @@ def test_control_path_collectives_use_a_gpu_tensor_under_rccl(monkeypatch):
         def optimizer_state_dict(self, lr, wd):
             return {}
 
-        def forward_backward(self, ts, labels, global_batch=None, loss_out=None, ncorrect_out=None):
+        def forward_backward(self, ts, labels, global_batch=None, loss_out=None, ncorrect_out=None, criterion=None):
             pass
 
         def optimizer_step(self, lr, wd):
