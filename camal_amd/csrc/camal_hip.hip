@@ -359,17 +359,19 @@ struct ProfScope {
 
 // ---- launches -------------------------------------------------------------------------
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: every kernel instantiation keeps its
-// high-water mark per device (table of kAttrDevices entries, one per instantiation, guarded by one mutex)
+// high-water mark per device (table of kAttrDevices entries, one per instantiation; raised under one mutex, read without it)
 constexpr int kAttrDevices = 64;
 std::mutex g_attr_mu;
 int ensure_lds_attr(const void* kern, size_t lds, size_t* table) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= kAttrDevices) return fail(CAMAL_ERR_ARG, "device index beyond the attribute table");
+    // fast path without the lock: the mark only ever grows, and it is published after the attribute is set
+    if (lds <= __atomic_load_n(&table[dev], __ATOMIC_ACQUIRE)) return 0;
     std::lock_guard<std::mutex> lock(g_attr_mu);
     if (lds > table[dev]) {
         HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        table[dev] = lds;
+        __atomic_store_n(&table[dev], lds, __ATOMIC_RELEASE);
     }
     return 0;
 }

@@ -92,22 +92,27 @@ int t_alloc(camal_trainer* t, void** p, size_t bytes) {
 
 inline int gs_blocks(size_t n, int cap = 4096) { return (int)std::min<size_t>((n + 255) / 256, (size_t)cap); }
 
-int wgrad_splits(const camal_trainer* t, const TLayer& l, int B, int* wps_out) {
+// workgroups wanted per (ci tile, tap group) pair of a layer: per_cu workgroups on every CU
+int wgrad_want(const camal_trainer* t, const TLayer& l) {
     const int tiles = (l.cin / 32) * ((l.ks + WG_TAPS - 1) / WG_TAPS);
-    static const int per_cu = getenv("CAMAL_WGRAD_PER_CU") ? std::max(1, atoi(getenv("CAMAL_WGRAD_PER_CU"))) : 3;
-    int want = std::max(1, (per_cu * t->num_cu) / std::max(1, tiles));
-    want = std::min(want, B);
-    const int wps = (B + want - 1) / want;
-    *wps_out = wps;
-    return (B + wps - 1) / wps;
+    // measured (5 members, 128 x 510, same box): 2 per CU 13.65 ms, 3 per CU 13.81 (more partials to write and reduce than
+    // the occupancy returns), whole windows per split (round 2) 13.72
+    static const int per_cu = getenv("CAMAL_WGRAD_PER_CU") ? std::max(1, atoi(getenv("CAMAL_WGRAD_PER_CU"))) : 2;
+    return std::max(1, (per_cu * t->num_cu) / std::max(1, tiles));
 }
 
-// the split count is not monotone in B (a ragged last batch can need more splits than a full one): the partial
-// buffer is sized for the largest count over every batch size the trainer accepts
-int wgrad_splits_max(const camal_trainer* t, const TLayer& l, int max_batch) {
-    int best = 1, wps;
-    for (int B = 1; B <= max_batch; ++B) best = std::max(best, wgrad_splits(t, l, B, &wps));
-    return best;
+// Splits of the (window, time tile) pairs of a batch, fixed by (B, L) alone: deterministic.  -> the number of splits,
+// *tps_out = tiles per split.  Never more than wgrad_want(): the partial buffer is sized for that many.
+int wgrad_splits(const camal_trainer* t, const TLayer& l, int B, int L, int* tps_out) {
+    const int TT = l.cout > 128 ? WgTT<256>::V : WgTT<128>::V;
+    const int total = B * ((L + TT - 1) / TT);
+    static const int by_window = getenv("CAMAL_WGRAD_BY_WINDOW") ? atoi(getenv("CAMAL_WGRAD_BY_WINDOW")) : 0;
+    int want = std::min(wgrad_want(t, l), total);
+    if (by_window) want = std::min(want, B);  // round 2's behaviour (A/B): whole windows per split
+    int tps = (total + want - 1) / want;
+    if (by_window) tps = (tps + (total / B) - 1) / (total / B) * (total / B);
+    *tps_out = tps;
+    return (total + tps - 1) / tps;
 }
 
 // ---- typed launch helpers -------------------------------------------------------------------
@@ -214,8 +219,8 @@ int t_bn_bwd(camal_trainer* t, hipStream_t s, const float* params, float* grads,
 // followed by a train-mode BatchNorm, which removes any per-channel constant: its exact
 // gradient is zero; torch's value is rounding noise of sum(dz)).
 int t_wgrad(camal_trainer* t, hipStream_t s, const TLayer& l, const float* dz, const float* ain, float* grads, int B, int L) {
-    int wps = 1;
-    const int nsplit = wgrad_splits(t, l, B, &wps);
+    int wps = 1;  // tiles per split
+    const int nsplit = wgrad_splits(t, l, B, L, &wps);
     const size_t need = (size_t)nsplit * l.ks * l.cout * l.cin;
     if (need > t->wg_part_floats) return fail(CAMAL_ERR_STATE, "wgrad partial buffer too small");
     // ceil(ks / WG_TAPS) tap groups of nearly equal size (9 = 5 + 4, 25 = 7 + 6 + 6 + 6), all in one grid:
@@ -348,13 +353,13 @@ int camal_trainer_create_widths(int device_id, int kernel_size, int max_batch, i
         const TLayer& l = t->lay.conv[i];
         A(&t->wpack[i], (size_t)l.cout * l.cin * l.ks);
         A(&t->wflip[i], (size_t)l.cout * l.cin * l.ks);
-        wg_max = std::max(wg_max, (size_t)wgrad_splits_max(t, l, max_batch) * l.ks * l.cout * l.cin);
+        wg_max = std::max(wg_max, (size_t)wgrad_want(t, l) * l.ks * l.cout * l.cin);
     }
     {
         const TLayer& l = t->lay.res[1];
         A(&t->wpack_res2, (size_t)l.cout * l.cin);
         A(&t->wflip_res2, (size_t)l.cout * l.cin);
-        wg_max = std::max(wg_max, (size_t)wgrad_splits_max(t, l, max_batch) * l.cout * l.cin);
+        wg_max = std::max(wg_max, (size_t)wgrad_want(t, l) * l.cout * l.cin);
     }
     t->wg_part_floats = wg_max;
     A(&t->wg_part, wg_max);

@@ -479,13 +479,16 @@ __device__ __forceinline__ void g_wait0(u32x4& d) { asm volatile("s_waitcnt vmcn
 template <int CIN, int COUT, int NTAP>
 __device__ __forceinline__ void wgrad_body(float (*s_dz)[COUT], float (*s_a)[32], const float* __restrict__ dz,
                                            const float* __restrict__ ain, float* __restrict__ part, int B, int L, int ks,
-                                           int windows_per_split, int j0, bool zero_pad) {
+                                           int tiles_per_split, int j0, bool zero_pad) {
     constexpr int TT = WgTT<COUT>::V;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int ci0 = blockIdx.x * 32;
     const int split = blockIdx.z, pad = ks >> 1;
-    const int b0 = split * windows_per_split, b1 = min(B, b0 + windows_per_split);
+    // a split = a run of consecutive (window, TT-step tile) pairs: finer than whole windows, so that layers with few
+    // (ci tile, tap group) pairs (64 channels: 2) still put three workgroups on every CU at a batch of 128
+    const int tpw = (L + TT - 1) / TT;
+    const int tile_lo = min(B * tpw, split * tiles_per_split), tile_hi = min(B * tpw, tile_lo + tiles_per_split);
 
     f32x16 acc[NTAP];
 #pragma unroll
@@ -557,12 +560,12 @@ __device__ __forceinline__ void wgrad_body(float (*s_dz)[COUT], float (*s_a)[32]
 #else
 #define WSTAMP(k) do {} while (0)
 #endif
-    const int tpw = (L + TT - 1) / TT, ntiles = (b1 - b0) * tpw;
+    const int ntiles = tile_hi - tile_lo;
+    int b = tile_lo / tpw, t0 = (tile_lo - b * tpw) * TT;
     if (ntiles > 0) {
-        fetch(b0, 0);
+        fetch(b, t0);
         landed();  // before the loop: whatever hipcc does to join these registers with the loop's happens on landed data
     }
-    int b = b0, t0 = 0;
     for (int tile = 0; tile < ntiles; ++tile) {
         WSTAMP(0);
         __syncthreads();
@@ -606,15 +609,15 @@ __device__ __forceinline__ void wgrad_body(float (*s_dz)[COUT], float (*s_a)[32]
 template <int CIN, int COUT, int NHI>
 __global__ __launch_bounds__(COUT * 2) void wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ ain,
                                                          float* __restrict__ part, int B, int L, int ks,
-                                                         int windows_per_split, int n_hi, bool zero_pad) {
+                                                         int tiles_per_split, int n_hi, bool zero_pad) {
     __shared__ float s_dz[WgTT<COUT>::V][COUT];
     __shared__ float s_a[WgTT<COUT>::V + WG_TAPS][32];
     const int y = blockIdx.y;
     if (y < n_hi) {
-        wgrad_body<CIN, COUT, NHI>(s_dz, s_a, dz, ain, part, B, L, ks, windows_per_split, y * NHI, zero_pad);
+        wgrad_body<CIN, COUT, NHI>(s_dz, s_a, dz, ain, part, B, L, ks, tiles_per_split, y * NHI, zero_pad);
     } else {
         if constexpr (NHI > 1)
-            wgrad_body<CIN, COUT, NHI - 1>(s_dz, s_a, dz, ain, part, B, L, ks, windows_per_split,
+            wgrad_body<CIN, COUT, NHI - 1>(s_dz, s_a, dz, ain, part, B, L, ks, tiles_per_split,
                                            n_hi * NHI + (y - n_hi) * (NHI - 1), zero_pad);
     }
 }
