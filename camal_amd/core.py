@@ -119,6 +119,21 @@ def _scaler_affine(scaler):
     return s2, s1
 
 
+def _appliance_affine(scaler):
+    """(mul, add) of NILMscaler.inverse_transform for the first appliance's power channel (torch_dataset.py:146-153 /
+    camal_amd.windows.NILMscaler): (1, 0) without a scaler or without appliance scaling; None for a scaler object whose
+    statistics cannot be read (the caller's own class: its inverse_transform is called on the whole array instead)."""
+    if scaler is None or getattr(scaler, "appliance_scaling_type", "?") is None:
+        return 1.0, 0.0
+    try:
+        a1, a2 = float(scaler.appliance_stat1[0]), float(scaler.appliance_stat2[0])
+        kind, pkind = scaler.appliance_scaling_type, getattr(scaler, "power_scaling_type", None)
+    except (AttributeError, IndexError, TypeError, ValueError):
+        return None
+    minmax = kind == "MinMax" or (kind == "SameAsPower" and pkind == "MinMax")
+    return ((a2 - a1) if minmax else a2), a1
+
+
 class CamAL(object):
     def __init__(self, n_predictors=5, device="cuda", batch_inference=128,
                  loc_metrics=NILMmetrics(), clf_metrics=Classifmetrics(), **resnet_kwargs):
@@ -284,27 +299,40 @@ class CamAL(object):
 
         data = data_test[:, 0, 0, :]
         want_power = appliance_mean_on_power is not None
+        mul, add = 1.0, 0.0
         if want_power:
             if scaler is None:
                 warnings.warn("No scaler provided for inverse_transform, are you sure you didn't scale the data for training?")
             mul, add = _scaler_affine(scaler)
-            res = self._localize_device(data, p_on=float(appliance_mean_on_power), scale_mul=mul, scale_add=add)
-        else:
-            res = self._localize_device(data)
-        prob_detect = res["prob"].cpu().numpy().reshape(-1, 1)
 
-        # localization metrics: states and powers stay on the device, only twelve sums come back
-        y_state = data_test[:, 1, 1, :].ravel().astype(dtype=int)
-        y = None
-        if want_power:
-            rescaled = scaler.inverse_transform(data_test) if scaler is not None else data_test
-            y = rescaled[:, 1, 0, :].ravel()
         if isinstance(self.loc_metrics, NILMmetrics):
-            from .metrics import nilm_sums_device
-            sums, n = nilm_sums_device(y=y, y_hat=res["power"] if want_power else None, y_state=y_state,
-                                       y_hat_state=res["state"])
+            # localization metrics without the [N, L] results ever leaving the device, at any N: windows, true powers
+            # and true states stream through the GPU in chunks, twelve sums per chunk come back (Ensemble.test_sums_host)
+            self._check_fitted_and_eval()
+            y_scaled, y_mul, y_add = None, 1.0, 0.0
+            if want_power:
+                aff = _appliance_affine(scaler)
+                if aff is None:  # a scaler object of the caller's own: its inverse_transform on the whole array
+                    y_scaled = scaler.inverse_transform(data_test)[:, 1, 0, :]
+                else:
+                    y_scaled, (y_mul, y_add) = data_test[:, 1, 0, :], aff
+            sums, n, prob = self._ensemble.test_sums_host(
+                data, y=y_scaled, y_state=data_test[:, 1, 1, :], gate_mode=int(bool(self.prefilter)),
+                p_on=float(appliance_mean_on_power) if want_power else None, scale_mul=mul, scale_add=add, y_mul=y_mul,
+                y_add=y_add, chunk_windows=self.stream_windows)
+            prob_detect = prob.reshape(-1, 1)
             metric_softlabel = self.loc_metrics.from_sums(sums, n, regression=want_power)
         else:  # a caller-supplied metric object gets host arrays, like the reference's
+            if want_power:
+                res = self._localize_device(data, p_on=float(appliance_mean_on_power), scale_mul=mul, scale_add=add)
+            else:
+                res = self._localize_device(data)
+            prob_detect = res["prob"].cpu().numpy().reshape(-1, 1)
+            y_state = data_test[:, 1, 1, :].ravel().astype(dtype=int)
+            y = None
+            if want_power:
+                rescaled = scaler.inverse_transform(data_test) if scaler is not None else data_test
+                y = rescaled[:, 1, 0, :].ravel()
             y_hat_state = res["state"].cpu().numpy().ravel().astype(dtype=int)
             y_hat = res["power"].cpu().numpy().astype(np.float64).ravel() if want_power else None
             metric_softlabel = self.loc_metrics(y, y_hat, y_state, y_hat_state) if want_power else \
@@ -357,6 +385,13 @@ class CamAL(object):
         if p_on is not None:
             out.append(power)
         return out[0] if len(out) == 1 else tuple(out)
+
+    def _check_fitted_and_eval(self):
+        if not self.is_fitted:
+            raise ValueError(
+                "CamAL instance is not fitted. Train CamAL or load a fitted instance of CamAL before trying to predict.")
+        if self.list_resnet_predictors is None:
+            self.eval()
 
     def _localize_device(self, data, y=None, w_ma=5, p_on=None, scale_mul=1.0, scale_add=0.0):
         """predict's checks + the fused HIP path; results stay on the device (dict of torch tensors)."""

@@ -351,6 +351,112 @@ class Ensemble:
             cur.wait_stream(s_comp)
         return states, prob, power
 
+    # --- CamAL.test at any N: windows, true powers and true states stream through the device, twelve sums come back ---
+    def test_sums_host(self, data, y=None, y_state=None, w_ma=5, gate_mode=0, p_on=None, scale_mul=1.0, scale_add=0.0,
+                       y_mul=1.0, y_add=0.0, chunk_windows=None):
+        """The sums behind ``NILMmetrics`` as ``CamAL.test`` needs them (core.py:199-231), for host arrays of any length:
+        ``data`` [N,L] (the scaled aggregate), ``y`` [N,L] true appliance power in the SCALED units of the data set
+        (``y * y_mul + y_add`` = NILMscaler.inverse_transform of that channel, applied chunk by chunk while staging; None:
+        no regression sums), ``y_state`` [N,L] true on/off labels.  Chunks go host -> device through pinned buffers under
+        the previous chunk's kernels; states and powers never leave the device, each chunk returns twelve doubles and its
+        windows' probabilities, added up on the host in chunk order (deterministic).
+        -> (sums [12] float64 as camal_nilm_sums, number of timesteps, prob [N] float64)."""
+        data = np.asarray(data)
+        N, L = data.shape
+        is64 = data.dtype != np.float32
+        want_power = p_on is not None and y is not None
+        chunk = max(1, min(int(chunk_windows or self.stream_chunk_windows(L)), N))
+        y64 = y is not None and np.asarray(y).dtype != np.float32
+        key = ("test", chunk, L, is64, y is not None, y64, y_state is not None)
+        dev = self.device
+        if getattr(self, "_tpipe_key", None) != key:
+            sets = []
+            with torch.cuda.device(dev):
+                for _ in range(2):
+                    b = {"in32": torch.empty((chunk, L), dtype=torch.float32).pin_memory(),
+                         "d_in32": torch.empty((chunk, L), dtype=torch.float32, device=dev),
+                         "d_state": torch.empty((chunk, L), dtype=torch.float32, device=dev),
+                         "d_power": torch.empty((chunk, L), dtype=torch.float32, device=dev),
+                         "d_prob": torch.empty((chunk,), dtype=torch.float64, device=dev),
+                         "prob": torch.empty((chunk,), dtype=torch.float64).pin_memory(),
+                         "d_sums": torch.empty(12, dtype=torch.float64, device=dev),
+                         "sums": torch.empty(12, dtype=torch.float64).pin_memory(),
+                         "ws": torch.empty(int(self.lib.camal_nilm_workspace_bytes(chunk * L)), dtype=torch.uint8, device=dev),
+                         "h2d": torch.cuda.Event(), "done": torch.cuda.Event(), "n": 0, "s": 0}
+                    if is64:
+                        b["in64"] = torch.empty((chunk, L), dtype=torch.float64).pin_memory()
+                        b["d_in64"] = torch.empty((chunk, L), dtype=torch.float64, device=dev)
+                    if y is not None:
+                        ydt = torch.float64 if y64 else torch.float32
+                        b["y"] = torch.empty((chunk, L), dtype=ydt).pin_memory()
+                        b["d_y"] = torch.empty((chunk, L), dtype=ydt, device=dev)
+                    if y_state is not None:
+                        b["ys"] = torch.empty((chunk, L), dtype=torch.int8).pin_memory()
+                        b["d_ys"] = torch.empty((chunk, L), dtype=torch.int8, device=dev)
+                    sets.append(b)
+                streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+            self.reserve(chunk, L)
+            self._tpipe_key, self._tpipe = key, (sets, streams)
+        sets, (s_h2d, s_comp) = self._tpipe
+        total = np.zeros(12, dtype=np.float64)
+        prob = np.empty((N,), dtype=np.float64)
+
+        def collect(b):
+            if b["n"] == 0:
+                return
+            b["done"].synchronize()
+            total[...] += b["sums"].numpy()
+            prob[b["s"]:b["s"] + b["n"]] = b["prob"][:b["n"]].numpy()
+            b["n"] = 0
+
+        cur = torch.cuda.current_stream(dev)
+        for b in sets:
+            b["n"] = 0
+        with torch.cuda.device(dev):
+            s_h2d.wait_stream(cur)
+            s_comp.wait_stream(cur)
+            for i, s in enumerate(range(0, N, chunk)):
+                n = min(chunk, N - s)
+                b = sets[i % 2]
+                collect(b)  # the chunk that used this set two steps ago is done: its buffers are free
+                b["in32"][:n].numpy()[...] = data[s:s + n]
+                if is64:
+                    b["in64"][:n].numpy()[...] = data[s:s + n]
+                if y is not None:
+                    yp = b["y"][:n].numpy()
+                    np.multiply(y[s:s + n], y_mul, out=yp, casting="unsafe")
+                    if y_add != 0.0:
+                        yp += y_add
+                if y_state is not None:
+                    b["ys"][:n].numpy()[...] = np.asarray(y_state[s:s + n]).astype(np.int64, copy=False)
+                with torch.cuda.stream(s_h2d):
+                    for k in ("in32", "in64", "y", "ys"):
+                        if k in b:
+                            b["d_" + ("in32" if k == "in32" else "in64" if k == "in64" else k)][:n].copy_(b[k][:n], non_blocking=True)
+                    b["h2d"].record(s_h2d)
+                with torch.cuda.stream(s_comp):
+                    s_comp.wait_event(b["h2d"])
+                    out = {"prob": b["d_prob"][:n], "state": b["d_state"][:n]}
+                    if want_power:
+                        out["power"] = b["d_power"][:n]
+                    self.localize(b["d_in32"][:n], x64=b["d_in64"][:n] if is64 else None, w_ma=w_ma, gate_mode=gate_mode,
+                                  pred_f64=is64, p_on=p_on if want_power else None, scale_mul=scale_mul, scale_add=scale_add, out=out)
+                    yd = b["d_y"][:n] if want_power else None
+                    _lib.check(self.lib.camal_nilm_sums(
+                        _lib.ptr(yd) if (yd is not None and not y64) else None, _lib.ptr(yd) if (yd is not None and y64) else None,
+                        _lib.ptr(b["d_power"][:n]) if want_power else None, _lib.ptr(b["d_ys"][:n]) if y_state is not None else None,
+                        _lib.ptr(b["d_state"][:n]) if y_state is not None else None, n * L, _lib.ptr(b["d_sums"]), _lib.ptr(b["ws"]),
+                        b["ws"].numel(), self._stream()))
+                    b["sums"].copy_(b["d_sums"], non_blocking=True)
+                    b["prob"][:n].copy_(b["d_prob"][:n], non_blocking=True)
+                    b["done"].record(s_comp)  # collect() waits for it on the host before this set is staged again
+                b["n"], b["s"] = n, s
+            nchunks = (N + chunk - 1) // chunk
+            for k in range(2):  # oldest first: the sums are added in chunk order
+                collect(sets[(nchunks + k) % 2])
+            cur.wait_stream(s_comp)
+        return total, N * L, prob
+
     # --- profiling ---------------------------------------------------------------------------
     def set_profiling(self, enabled=True):
         _lib.check(self.lib.camal_set_profiling(self._h, int(bool(enabled))))

@@ -278,3 +278,40 @@ def test_predict_over_several_gpus_from_one_process():
     three.states_dtype = np.int8
     s3 = three.predict(x)
     assert s3.dtype == np.int8 and np.array_equal(s3, s1.astype(np.int8))
+
+
+def test_camal_test_streams_at_any_size():
+    """CamAL.test (core.py:191-240) with the windows, true powers and true states streamed through the device in chunks
+    (Ensemble.test_sums_host): twelve sums per chunk, nothing of size [N, L] ever comes back.  Against the host route —
+    predict + the reference's NILMmetrics formulas on host arrays, inverse scaling through NILMscaler.inverse_transform —
+    for a scaler that scales the appliance channel too, with chunks smaller than the test set and ragged."""
+    from camal_amd import synth
+    from camal_amd.metrics import NILMmetrics
+    from camal_amd.windows import NILMscaler
+    c = load_case("ensemble_l256")
+    n, L = 45, c["data"].shape[1]
+    x = synth.ukdale_windows(n, L, seed=51).astype(np.float64)  # kW
+    camal = _fitted_camal(c)
+    states, prob = camal.predict(x, return_prob=True)
+    rng = np.random.default_rng(3)
+    true_state = ((states > 0) ^ (rng.random(states.shape) < 0.1)).astype(np.float64)
+    true_state[::4] = 0.0  # windows without the appliance: both weak labels occur (ROC AUC needs them)
+    data4 = np.zeros((n, 2, 2, L))
+    data4[:, 0, 0, :] = x * 1000.0                                  # W
+    data4[:, 1, 0, :] = true_state * rng.uniform(1500, 2500, size=states.shape)
+    data4[:, 1, 1, :] = true_state
+    sc = NILMscaler(power_scaling_type=1000, appliance_scaling_type="SameAsPower")
+    scaled = sc.fit_transform(data4.copy())
+    assert np.allclose(scaled[:, 0, 0, :], x)
+    # host route: the reference's flow on host arrays
+    y = sc.inverse_transform(scaled)[:, 1, 0, :].ravel()
+    y_hat = np.minimum(states.astype(int) * 2000.0, scaled[:, 0, 0, :] * 1000.0).ravel()
+    want = NILMmetrics()(y, y_hat, scaled[:, 1, 1, :].ravel().astype(int), states.ravel().astype(int))
+    for chunk in (None, 7, 16):
+        camal.stream_windows = chunk
+        loc, clf = camal.test(scaled, appliance_mean_on_power=2000.0, scaler=sc)
+        assert loc == want, (chunk, loc, want)
+        assert clf["ACCURACY"] >= 0.0 and "AP" in clf
+    camal.stream_windows = 7
+    loc2, _ = camal.test(scaled)
+    assert loc2 == NILMmetrics()(y_state=scaled[:, 1, 1, :].ravel().astype(int), y_hat_state=states.ravel().astype(int))
