@@ -249,6 +249,13 @@ def test_streaming_predict_compact_dtypes_and_caller_arrays():
     assert w64.dtype == np.float64 and np.array_equal(w64, rw.astype(np.float64))
     with pytest.raises(ValueError):
         ens.localize_host(x, out={"states": np.empty((N, L + 1))})
+    # the tiled post-processing kernel's byte stores: a length that is no multiple of 4, a 4-step moving average, float64 data
+    x2 = x[:50, :131].astype(np.float64)
+    r2 = ens.localize(x2.astype(np.float32), x64=x2, pred_f64=True, w_ma=4, p_on=2000.0, scale_mul=1000.0)
+    s2, p2, w2 = ens.localize_host(x2, w_ma=4, p_on=2000.0, scale_mul=1000.0, chunk_windows=16)
+    rs2 = r2["state"].cpu().numpy()
+    assert np.array_equal(s2, rs2.astype(np.float64)) and np.array_equal(np.signbit(s2), np.signbit(rs2))
+    assert np.array_equal(p2, r2["prob"].cpu().numpy()) and np.array_equal(w2, r2["power"].cpu().numpy().astype(np.float64))
     ens.close()
 
 
