@@ -165,10 +165,12 @@ class CamAL(object):
         # and HIP stream with its own shuffle generator (one member's short kernels fill the gaps of another's).
         # Not with data-parallel training over several ranks (their collectives must be issued in one order).
         self.member_streams = 1
-        # predict() over several GPUs from this ONE process (the reference's all_gpu idea, torch_trainer.py:82-90, for
-        # inference): ``devices`` = ["cuda:0", "cuda:1", ...], or ``all_devices = True`` for every visible GPU.  Every
-        # GPU holds all the members and takes a contiguous block of the windows on a host thread of its own; results
-        # land in disjoint slices of the output arrays; no collective.  None / False: ``device`` alone.
+        # Several GPUs from this ONE process (what all_gpu=True is for in the reference, torch_trainer.py:82-90):
+        # ``devices`` = ["cuda:0", "cuda:1", ...], or ``all_devices = True`` for every visible GPU.
+        # predict(): every GPU holds all the members and takes a contiguous block of the windows on a host thread of its
+        # own; results land in disjoint slices of the output arrays; no collective.
+        # train(): the (kernel size, try) candidates go round robin over the GPUs, each trained whole on one GPU by a
+        # host thread (they are independent, core.py:104-158): no gradient exchange.  None / False: ``device`` alone.
         self.devices = None
         self.all_devices = False
         # dtypes of predict()'s arrays; the reference's are float64 (core.py:449 convolves against float64 ones).
@@ -208,8 +210,15 @@ class CamAL(object):
         rank, _, world = parallel.world_info()
         spread = bool(self.member_parallel) and world > 1
         local_results = {}
+        train_devices = self._device_list()
+        if train_devices is None and training_kwargs["all_gpu"] and world == 1 and torch.cuda.device_count() > 1:
+            # the reference's all_gpu=True (nn.DataParallel over every GPU, torch_trainer.py:82-90) from a single
+            # process: every GPU is used, by giving each a candidate of its own instead of a slice of every batch
+            train_devices = [f"cuda:{i}" for i in range(torch.cuda.device_count())]
+        over_devices = world == 1 and train_devices is not None and len(train_devices) > 1
 
-        def run_candidate(idx, kernel_size, nth_try, generator=None, resnet_inst=None):
+        def run_candidate(idx, kernel_size, nth_try, generator=None, resnet_inst=None, device=None):
+            device = self.device if device is None else device
             if resnet_inst is None:
                 resnet_inst = CamALResNet(kernel_size=kernel_size, **self.resnet_kwargs)
             train_loader = TSLoader(X_train, y_train, batch_size=training_kwargs["batch_size"], shuffle=True, generator=generator)
@@ -219,8 +228,8 @@ class CamAL(object):
                 resnet_inst, train_loader=train_loader, valid_loader=valid_loader,
                 learning_rate=training_kwargs["lr"], weight_decay=training_kwargs["weight_decay"],
                 patience_es=training_kwargs["patience_es"], patience_rlr=training_kwargs["patience_rlr"],
-                n_warmup_epochs=training_kwargs["n_warmup_epochs"], device=self.device,
-                all_gpu=training_kwargs["all_gpu"], data_parallel=not spread)
+                n_warmup_epochs=training_kwargs["n_warmup_epochs"], device=device,
+                all_gpu=training_kwargs["all_gpu"] and not over_devices, data_parallel=not spread and not over_devices)
             clf_trainer.train(training_kwargs["epochs"])
             clf_trainer.restore_best_weights()
             loss_eval, _ = clf_trainer.evaluate(test_loader)
@@ -239,25 +248,31 @@ class CamAL(object):
                 idx_clf += 1
 
         n_side = int(self.member_streams or 1)
-        if n_side > 1 and (world == 1 or spread) and len(jobs) > 1:
+        if (n_side > 1 or over_devices) and (world == 1 or spread) and len(jobs) > 1:
             import torch
             from concurrent.futures import ThreadPoolExecutor
-            dev = torch.device(self.device)
+            # one process, several GPUs (self.devices / all_devices): the candidates go round robin over the GPUs, each
+            # trained whole on its GPU by a host thread, member_streams of them side by side per GPU; no gradient exchange
+            # (the candidates are independent, core.py:104-158) — what all_gpu=True is for in the reference, without
+            # splitting any batch
+            devs = [torch.device(d) for d in train_devices] if over_devices else [torch.device(self.device)]
             base = int(torch.empty((), dtype=torch.int64).random_().item())  # one draw: reproducible under manual_seed
             # initial weights come from the global RNG: drawn here, in candidate order, before the threads start
             models = {job[0]: CamALResNet(kernel_size=job[1], **self.resnet_kwargs) for job in jobs}
+            slot = {job[0]: i for i, job in enumerate(jobs)}
 
             def threaded(job):
                 idx = job[0]
+                dev = devs[slot[idx] % len(devs)]
                 gen = torch.Generator().manual_seed((base + 7919 * idx) % (1 << 62))
                 with torch.cuda.device(dev):
                     stream = torch.cuda.Stream(dev)
                     with torch.cuda.stream(stream):
-                        out = run_candidate(*job, generator=gen, resnet_inst=models[idx])
+                        out = run_candidate(*job, generator=gen, resnet_inst=models[idx], device=str(dev))
                     stream.synchronize()
                 return idx, out
 
-            with ThreadPoolExecutor(max_workers=n_side) as pool:
+            with ThreadPoolExecutor(max_workers=n_side * len(devs)) as pool:
                 for idx, out in pool.map(threaded, jobs):
                     local_results[f"Predictor_{idx}"] = out
         else:
@@ -427,6 +442,14 @@ class CamAL(object):
             self.device = device
         return
 
+    def _device_list(self):
+        """``devices`` as given, every visible GPU with ``all_devices``, else None (``device`` alone)."""
+        if self.devices:
+            return [str(d) for d in self.devices]
+        if self.all_devices:
+            return [f"cuda:{i}" for i in range(torch.cuda.device_count())]
+        return None
+
     # ------------------------------------------------------------------ eval (core.py:366-413)
     def eval(self) -> None:
         if not self.is_fitted:
@@ -449,9 +472,7 @@ class CamAL(object):
         self.list_cam_predictors = list_cam_predictors
         for ens in self._ensembles or ([self._ensemble] if self._ensemble is not None else []):
             ens.close()
-        devices = list(self.devices) if self.devices else None
-        if devices is None and self.all_devices:
-            devices = [f"cuda:{i}" for i in range(torch.cuda.device_count())]
+        devices = self._device_list()
         if devices:
             # the first entry is the instance's own device: CAM.run, test() and the mirror classes live there
             self._ensembles = [Ensemble(sds, device=d, precision=self.precision) for d in devices]

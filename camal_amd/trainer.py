@@ -424,8 +424,9 @@ class BasedClassifTrainer(object):
             # here data-parallel training is one process per GPU, which a single process cannot become by itself
             warnings.warn("all_gpu=True: this process trains on one GPU.  Multi-GPU data-parallel training is one process "
                           "per GPU: launch the same script with `python -m torch.distributed.run --nproc-per-node N ...` "
-                          "and call torch.distributed.init_process_group('nccl') first; or set CamAL.member_parallel = "
-                          "True there to train the ensemble's members on different GPUs with no gradient exchange.")
+                          "and call torch.distributed.init_process_group('nccl') first.  CamAL.train(all_gpu=True) / "
+                          "CamAL.devices use every GPU from one process by training the ensemble's members on different "
+                          "GPUs (no gradient exchange).")
         configure_loader_sync(train_loader, data_parallel, self.engine.device)
 
     def _init_host(self, model, train_loader, valid_loader, learning_rate, weight_decay, patience_es, patience_rlr,

@@ -379,3 +379,30 @@ def test_resident_training_set_equals_per_batch_copies():
     a, b = run(True), run(False)
     assert a[0] == b[0] and a[1] == b[1]
     assert all(np.array_equal(a[2][k], b[2][k]) for k in a[2])
+
+
+def test_camal_train_over_devices_from_one_process():
+    """CamAL.devices for train(): the candidates go round robin over the listed GPUs, one host thread each, no gradient
+    exchange.  One GPU here: two entries for cuda:0 stand in for two GPUs; every member's histories equal the
+    member_streams run with the same seed (same per-candidate generators), and predict then shards over the same list."""
+    import torch
+    from camal_amd import CamAL, synth
+    x, y = synth.ideal_windows(96, 64, seed=3)
+    logs = []
+    for mode in ("devices", "streams"):
+        torch.manual_seed(11)
+        camal = CamAL(n_predictors=2, device="cuda:0")
+        if mode == "devices":
+            camal.devices = ["cuda:0", "cuda:0"]
+        else:
+            camal.member_streams = 2
+        camal.train((x[:64], y[:64]), (x[64:80], y[64:80]), (x[80:], y[80:]), list_kernel_sizes=[5, 7, 9], epochs=2, batch_size=16)
+        logs.append(camal.camal_logs)
+        if mode == "devices":
+            assert len(camal._ensembles) == 2
+            assert camal.predict(x[80:]).shape == (16, 64)
+    a, b = logs
+    assert a["camal_predictors_id"] == b["camal_predictors_id"]
+    for n in a["ensemble_training_logs"]:
+        la, lb = a["ensemble_training_logs"][n], b["ensemble_training_logs"][n]
+        assert la["loss_train_history"] == lb["loss_train_history"] and la["loss_valid_history"] == lb["loss_valid_history"]
