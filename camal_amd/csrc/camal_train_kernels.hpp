@@ -467,6 +467,13 @@ __global__ __launch_bounds__(256) void fold_edges_kernel(const float* __restrict
 // own branch, LDS read and lgkmcnt(0) (the kernel ran at 0.32 of the fp32 peak).
 // timesteps per staged tile: 64, or 32 for 256 out-channels (the dz tile must fit the 64 KiB of static LDS)
 template <int COUT> struct WgTT { static constexpr int V = COUT > 128 ? 32 : WG_TT; };
+// 32-wide ci tiles per workgroup: a workgroup is COUT / 32 waves per ci tile, and with fewer than four waves the CU's
+// dispatcher stacks the workgroups on the same SIMDs (two 2-wave workgroups of the 64 -> 64 layers shared SIMD 0 / 1 and
+// ran at half speed each, 60 TF): narrow layers take 2 (64 out-channels) or 4 (32) ci tiles, which also share one dz tile
+template <int CIN, int COUT> struct WgCIW {
+    static constexpr int WPT = COUT / 32;  // waves per ci tile
+    static constexpr int V = WPT >= 4 ? 1 : ((CIN / 32) < (4 / WPT) ? (CIN / 32) : (4 / WPT));
+};
 
 // A prefetch hipcc's wait bookkeeping does not see (as the weight ring of the convolutions, camal_kernels.hpp w_load):
 // left to the compiler, the next tile's loads were followed by s_waitcnt vmcnt(10) -- the first of them back -- in front
@@ -480,10 +487,13 @@ template <int CIN, int COUT, int NTAP>
 __device__ __forceinline__ void wgrad_body(float (*s_dz)[COUT], float (*s_a)[32], const float* __restrict__ dz,
                                            const float* __restrict__ ain, float* __restrict__ part, int B, int L, int ks,
                                            int tiles_per_split, int j0, bool zero_pad) {
-    constexpr int TT = WgTT<COUT>::V;
+    constexpr int TT = WgTT<COUT>::V, CIW = WgCIW<CIN, COUT>::V, WPT = COUT / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const int ci0 = blockIdx.x * 32;
+    const int cot = wave % WPT, cis = wave / WPT;        // this wave's co tile and ci tile inside the workgroup
+    const int cig0 = blockIdx.x * CIW * 32;              // first input channel of the workgroup
+    const int ci0 = cig0 + cis * 32;
+    const int arow0 = cis * (TT + WG_TAPS);              // this wave's ci tile inside s_a
     const int split = blockIdx.z, pad = ks >> 1;
     // a split = a run of consecutive (window, TT-step tile) pairs: finer than whole windows, so that layers with few
     // (ci tile, tap group) pairs (64 channels: 2) still put three workgroups on every CU at a batch of 128
@@ -498,9 +508,9 @@ __device__ __forceinline__ void wgrad_body(float (*s_dz)[COUT], float (*s_a)[32]
 
     // The next tile's rows travel from global memory into registers while this tile's MFMAs run (one LDS copy of
     // each tile: the waves of the CU's other workgroup cover the short register -> LDS phase).
-    constexpr int NTH = COUT * 2;
-    constexpr int DZ_PER = TT * (COUT / 4) / NTH;                  // = 8 float4 of dz per lane
-    constexpr int A_Q = (TT + NTAP - 1) * 8, A_PER = (A_Q + NTH - 1) / NTH;
+    constexpr int NTH = COUT * 2 * CIW;
+    constexpr int DZ_PER = TT * (COUT / 4) / NTH;                  // float4 of dz per lane (8 with one ci tile)
+    constexpr int A_Q1 = (TT + NTAP - 1) * 8, A_Q = A_Q1 * CIW, A_PER = (A_Q + NTH - 1) / NTH;
     static_assert(DZ_PER * NTH == TT * (COUT / 4), "dz tile divides over the workgroup");
     u32x4 rdz[DZ_PER], ra[A_PER];
 #pragma unroll
@@ -525,9 +535,10 @@ __device__ __forceinline__ void wgrad_body(float (*s_dz)[COUT], float (*s_a)[32]
 #pragma unroll
         for (int u = 0; u < A_PER; ++u) {
             const int q = min((int)threadIdx.x + u * NTH, A_Q - 1);
-            const int p = t0 + j0 - pad + (q >> 3);
+            const int sub = q / A_Q1, w = q - sub * A_Q1;  // ci tile, chunk inside it
+            const int p = t0 + j0 - pad + (w >> 3);
             const int pc = p < 0 ? 0 : (p > L - 1 ? L - 1 : p);
-            g_load16(ra[u], ain + ((size_t)b * L + pc) * CIN + ci0 + (q & 7) * 4);
+            g_load16(ra[u], ain + ((size_t)b * L + pc) * CIN + cig0 + sub * 32 + (w & 7) * 4);
         }
     };
     auto landed = [&]() {  // every load of the last fetch has arrived
@@ -549,8 +560,10 @@ __device__ __forceinline__ void wgrad_body(float (*s_dz)[COUT], float (*s_a)[32]
         for (int u = 0; u < A_PER; ++u) {
             const int q = threadIdx.x + u * NTH;
             if (q < A_Q) {
-                const int p = t0 + j0 - pad + (q >> 3);
-                *reinterpret_cast<float4*>(&s_a[q >> 3][(q & 7) * 4]) = (zero_pad && (p < 0 || p > L - 1)) ? zero4 : __builtin_bit_cast(float4, ra[u]);
+                const int sub = q / A_Q1, w = q - sub * A_Q1;
+                const int p = t0 + j0 - pad + (w >> 3);
+                *reinterpret_cast<float4*>(&s_a[sub * (TT + WG_TAPS) + (w >> 3)][(w & 7) * 4]) =
+                    (zero_pad && (p < 0 || p > L - 1)) ? zero4 : __builtin_bit_cast(float4, ra[u]);
             }
         }
     };
@@ -583,20 +596,20 @@ __device__ __forceinline__ void wgrad_body(float (*s_dz)[COUT], float (*s_a)[32]
         WSTAMP(4);
 #pragma unroll 16
         for (int s = 0; s < TT / 2; ++s) {
-            const float av = s_dz[2 * s + h][32 * wave + i];
+            const float av = s_dz[2 * s + h][32 * cot + i];
 #pragma unroll
             for (int j = 0; j < NTAP; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s_a[2 * s + h + j][i], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s_a[arow0 + 2 * s + h + j][i], acc[j], 0, 0, 0);
         }
         WSTAMP(5);
         b = nb;
         t0 = nt0;
     }
     landed();  // unconditionally: the last, unused prefetch is still in flight and nothing may reuse its registers before it lands
-    // acc[j][reg]: column ci = ci0 + i, row co = 32 wave + (reg&3) + 8 (reg>>2) + 4 h
+    // acc[j][reg]: column ci = ci0 + i, row co = 32 cot + (reg&3) + 8 (reg>>2) + 4 h
 #pragma unroll
     for (int j = 0; j < NTAP; ++j) {
-            float* po = part + (((size_t)split * ks + (j0 + j)) * COUT + 32 * wave) * CIN + ci0 + i;
+            float* po = part + (((size_t)split * ks + (j0 + j)) * COUT + 32 * cot) * CIN + ci0 + i;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) po[(size_t)((reg & 3) + 8 * (reg >> 2) + 4 * h) * CIN] = acc[j][reg];
         }
@@ -607,11 +620,11 @@ __device__ __forceinline__ void wgrad_body(float (*s_dz)[COUT], float (*s_a)[32]
 // 0.69 busy on a single 7- or 8-tap group (512 workgroups), 0.83 on k = 25's four groups.  Groups of at most 4 taps
 // to get there on every layer: 3-5 % slower, a dz tile staged per 4 x 32 MFMAs costs more than the occupancy gains.
 template <int CIN, int COUT, int NHI>
-__global__ __launch_bounds__(COUT * 2) void wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ ain,
+__global__ __launch_bounds__(COUT * 2 * WgCIW<CIN, COUT>::V) void wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ ain,
                                                          float* __restrict__ part, int B, int L, int ks,
                                                          int tiles_per_split, int n_hi, bool zero_pad) {
     __shared__ float s_dz[WgTT<COUT>::V][COUT];
-    __shared__ float s_a[WgTT<COUT>::V + WG_TAPS][32];
+    __shared__ float s_a[WgCIW<CIN, COUT>::V * (WgTT<COUT>::V + WG_TAPS)][32];
     const int y = blockIdx.y;
     if (y < n_hi) {
         wgrad_body<CIN, COUT, NHI>(s_dz, s_a, dz, ain, part, B, L, ks, tiles_per_split, y * NHI, zero_pad);
