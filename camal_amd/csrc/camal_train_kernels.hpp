@@ -467,9 +467,9 @@ __global__ __launch_bounds__(256) void fold_edges_kernel(const float* __restrict
 // own branch, LDS read and lgkmcnt(0) (the kernel ran at 0.32 of the fp32 peak).
 // timesteps per staged tile: 64, or 32 for 256 out-channels (the dz tile must fit the 64 KiB of static LDS)
 template <int COUT> struct WgTT { static constexpr int V = COUT > 128 ? 32 : WG_TT; };
-// 32-wide ci tiles per workgroup: a workgroup is COUT / 32 waves per ci tile, and with fewer than four waves the CU's
-// dispatcher stacks the workgroups on the same SIMDs (two 2-wave workgroups of the 64 -> 64 layers shared SIMD 0 / 1 and
-// ran at half speed each, 60 TF): narrow layers take 2 (64 out-channels) or 4 (32) ci tiles, which also share one dz tile
+// 32-wide ci tiles per workgroup: a workgroup is COUT / 32 waves per ci tile; narrow layers take 2 (64 out-channels) or
+// 4 (32) ci tiles so that a workgroup is four waves, one per SIMD, sharing one dz tile.  Measured neutral on the 64 -> 64
+// layers (62 us for 3.7 GFLOP whatever the workgroup count: 256 or 512 workgroups, two or four waves each).
 template <int CIN, int COUT> struct WgCIW {
     static constexpr int WPT = COUT / 32;  // waves per ci tile
     static constexpr int V = WPT >= 4 ? 1 : ((CIN / 32) < (4 / WPT) ? (CIN / 32) : (4 / WPT));
