@@ -485,6 +485,12 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    # stdout carries ONE JSON line and nothing else: libraries that print there (RCCL's version banner at communicator
+    # creation) are sent to stderr for the whole run; the line itself goes to the real stdout
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     dist = None
     dev = f"cuda:{local_rank}"
@@ -507,7 +513,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "max_rank_seen": int(t.item())}), flush=True)
+            print(json.dumps({"dry_run": True, "n_gpus": world, "max_rank_seen": int(t.item())}), file=real_stdout, flush=True)
         return
 
     R = Ranks(rank, world, dev, dist)
@@ -524,7 +530,7 @@ def main():
 
     def emit():
         if rank == 0 and line and printed.acquire(blocking=False):
-            print(json.dumps(line), flush=True)
+            print(json.dumps(line), file=real_stdout, flush=True)
 
     def on_deadline():  # a hung collective or kernel must not cost the driver the line rank 0 already has
         for n in also:
