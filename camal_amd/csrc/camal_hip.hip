@@ -943,7 +943,11 @@ static int localize_impl(camal_ctx* c, const float* x, const double* x64, const 
         // one post-processing launch per group of ng windows; the group's CAM rows, logits and row maxima
         // wait in the workspace as [E][ng][..]
         const int ng = std::min(PB, B - g0);
-        HIP_TRY(hipMemsetAsync(w.cmax, 0, (size_t)E * ng * 4, s));
+        {
+            const size_t nz = (size_t)E * ng;
+            hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)std::min<size_t>((nz + 255) / 256, 1024)), dim3(256), 0, s, w.cmax, nz);
+            HIP_TRY(hipGetLastError());
+        }
         HeaderArgs h;
         for (int c0 = g0; c0 < g0 + ng; c0 += BC) {
             const int n = std::min(BC, g0 + ng - c0);

@@ -1691,6 +1691,12 @@ __global__ __launch_bounds__(256) void cam_dot_kernel(const DT* __restrict__ fea
     }
 }
 
+// Zero fill as a kernel: camal_localize clears the row maxima with it.  (hipMemsetAsync on this ROCm is not replayed as
+// part of a captured HIP graph: a replay on new inputs kept the maxima of the capture-time call.)
+__global__ __launch_bounds__(256) void zero_fill_kernel(float* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0.f;
+}
+
 // logits[b][k] = (sum over tiles of part[b][tile][k]) / L + b_fc[k]   (camal_resnet.py:23)
 __device__ __forceinline__ void member_logits(const float* part, int ntiles, int L, const float* bfc, float& l0,
                                               float& l1) {

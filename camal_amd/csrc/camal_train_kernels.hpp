@@ -467,9 +467,10 @@ __global__ __launch_bounds__(256) void fold_edges_kernel(const float* __restrict
 // own branch, LDS read and lgkmcnt(0) (the kernel ran at 0.32 of the fp32 peak).
 // timesteps per staged tile: 64, or 32 for 256 out-channels (the dz tile must fit the 64 KiB of static LDS)
 template <int COUT> struct WgTT { static constexpr int V = COUT > 128 ? 32 : WG_TT; };
-// 32-wide ci tiles per workgroup: a workgroup is COUT / 32 waves per ci tile; narrow layers take 2 (64 out-channels) or
-// 4 (32) ci tiles so that a workgroup is four waves, one per SIMD, sharing one dz tile.  Measured neutral on the 64 -> 64
-// layers (62 us for 3.7 GFLOP whatever the workgroup count: 256 or 512 workgroups, two or four waves each).
+// 32-wide ci tiles per workgroup: a workgroup is COUT / 32 waves per ci tile, and with fewer than four waves the CU's
+// dispatcher stacks the workgroups on the same SIMDs (the two-wave workgroups of the 64 -> 64 layers shared SIMD 0 / 1
+// whatever their number: 60 TF).  Narrow layers take 2 (64 out-channels) or 4 (32) ci tiles: four waves, one per SIMD,
+// sharing one dz tile.  64 -> 64, 128 x 510: 7 taps 62 -> 38 us, 3 taps 33 -> 20 us.
 template <int CIN, int COUT> struct WgCIW {
     static constexpr int WPT = COUT / 32;  // waves per ci tile
     static constexpr int V = WPT >= 4 ? 1 : ((CIN / 32) < (4 / WPT) ? (CIN / 32) : (4 / WPT));
@@ -620,7 +621,7 @@ __device__ __forceinline__ void wgrad_body(float (*s_dz)[COUT], float (*s_a)[32]
 // 0.69 busy on a single 7- or 8-tap group (512 workgroups), 0.83 on k = 25's four groups.  Groups of at most 4 taps
 // to get there on every layer: 3-5 % slower, a dz tile staged per 4 x 32 MFMAs costs more than the occupancy gains.
 template <int CIN, int COUT, int NHI>
-__global__ __launch_bounds__(COUT * 2 * WgCIW<CIN, COUT>::V) void wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ ain,
+__global__ __launch_bounds__((COUT * 2 * WgCIW<CIN, COUT>::V)) void wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ ain,
                                                          float* __restrict__ part, int B, int L, int ks,
                                                          int tiles_per_split, int n_hi, bool zero_pad) {
     __shared__ float s_dz[WgTT<COUT>::V][COUT];
