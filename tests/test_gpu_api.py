@@ -256,6 +256,11 @@ def test_streaming_predict_compact_dtypes_and_caller_arrays():
     rs2 = r2["state"].cpu().numpy()
     assert np.array_equal(s2, rs2.astype(np.float64)) and np.array_equal(np.signbit(s2), np.signbit(rs2))
     assert np.array_equal(p2, r2["prob"].cpu().numpy()) and np.array_equal(w2, r2["power"].cpu().numpy().astype(np.float64))
+    # one window (fewer rows than worker threads) and none at all
+    s1, p1, _ = ens.localize_host(x2[:1], w_ma=4)
+    assert np.array_equal(s1, rs2[:1].astype(np.float64)) and p1.shape == (1,)
+    s0, p0, w0 = ens.localize_host(x2[:0], p_on=2000.0)
+    assert s0.shape == (0, 131) and p0.shape == (0,) and w0.shape == (0, 131)
     ens.close()
 
 
