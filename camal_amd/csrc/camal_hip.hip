@@ -392,7 +392,8 @@ int launch_conv_w(camal_ctx* c, int num_cu, size_t lds_per_cu, int cam_row, hipS
     const int tpw = (L_out + G::TN - 1) / G::TN;
     const long long total = (long long)tpw * BC;
     if (total > 0x7fffffffLL) return fail(CAMAL_ERR_ARG, "too many tiles in one pass");
-    const int per_cu = std::max(1, std::min(4, (int)(lds_per_cu / lds)));
+    static const int per_cu_cap = getenv("CAMAL_CONV_PER_CU") ? std::max(1, atoi(getenv("CAMAL_CONV_PER_CU"))) : 4;
+    const int per_cu = std::max(1, std::min(per_cu_cap, (int)(lds_per_cu / lds)));
     const int grid = (int)std::min<long long>(total, (long long)num_cu * per_cu);
     ProfScope ps(c, s, HEAD ? 2 : 1);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(G::THREADS), lds, s, (const DT*)in, (const uint4*)wpack, bias,
