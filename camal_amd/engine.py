@@ -268,7 +268,8 @@ class Ensemble:
         array, core.py:286): that is the default; ``states_dtype`` / ``power_dtype`` (e.g. int8 / float32: 5 instead
         of 16 bytes per timestamp of host memory) and ``out`` = {"states", "prob", "power"} arrays to fill in place
         (np.memmap included) keep the host side bounded at that scale.  Same numbers as one call of ``localize`` on
-        everything: windows are independent."""
+        everything: windows are independent.  Not re-entrant: one call at a time per Ensemble (the pinned buffers and
+        streams are the Ensemble's; several GPUs = several Ensembles, ``localize_host_sharded``)."""
         data = np.asarray(data)
         N, L = data.shape
         is64 = data.dtype != np.float32
