@@ -222,6 +222,20 @@ def run_inference(name, wl, steps, warmup, R, args, min_seconds=0.0, with_cpu_in
             rp["frac_of_copy"] = post_gbs / copy if copy else None
         except Exception as e:  # noqa: BLE001 — a measurement extra, never fatal
             res["roofline_post"]["copy_gbs"] = f"probe failed: {e}"
+        # the same box's register-only MFMA loops (tools/mfma_probe.hip) beside the spec peak: on constant operands the
+        # pipes reach the spec figure; on random bf16 operands the part lowers its clock (data toggling against the power
+        # limit) and the loop that does nothing else stops near 0.76-0.79 of it
+        try:
+            if args.no_extras:
+                raise RuntimeError("skipped (--no-extras)")
+            import mfma_probe
+            rf = res["roofline"]
+            kinds = ("bf16", "bf16_random") if wl["precision"] == "bf16" else ("fp32",)
+            rf["mfma_probe_tflops"] = {k: mfma_probe.probe(k, device=dev, waves=(8,), blocks=(1024,), launch_ms=(20.0,)) for k in kinds}
+            ceil = rf["mfma_probe_tflops"].get("bf16_random") or rf["mfma_probe_tflops"].get("fp32")
+            rf["frac_of_probe"] = achieved / ceil if ceil else None
+        except Exception as e:  # noqa: BLE001
+            res["roofline"]["mfma_probe_tflops"] = f"probe failed: {e}"
     if R.rank == 0 and name == "ensemble_bf16" and R.world == 1 and not args.no_extras:
         res["host_to_host"] = host_to_host(ens, wl, B * steps / dt)
     ens.close()
