@@ -9,6 +9,8 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <tuple>
+#include <utility>
 #include <vector>
 
 using namespace camal;
@@ -338,20 +340,55 @@ int ensure_workspace(camal_ctx* c, int BC, int PB, int L, Workspace* w) {
 }
 
 // ---- profiling ------------------------------------------------------------------------
+// Two forms.  ProfScope(ctx, stream, cls): an event pair recorded on the stream around whatever the scope launches.
+// ProfScope(ctx, stream, cls, kOneKernel) + launch(...): the scope's ONE kernel carries the pair itself
+// (hipExtLaunchKernel's start / stop events = the dispatch's own begin and end stamps, what rocprofv3 reports); an
+// event pair recorded around a 13-25 us kernel also times the hand-offs between the stream's packets (about 3 us).
+struct OneKernel {};
+constexpr OneKernel kOneKernel{};
+
 struct ProfScope {
-    camal_ctx* c; hipStream_t s; ProfRec rec; bool on;
-    ProfScope(camal_ctx* ctx, hipStream_t st, int cls) : c(ctx), s(st), on(ctx && ctx->prof) {
-        if (!on) return;
+    camal_ctx* c; hipStream_t s; ProfRec rec; bool on; bool one = false, launched = false;
+    void take(int cls) {
         while (c->pool.size() < c->pool_used + 2) {
             hipEvent_t e;
             if (hipEventCreate(&e) != hipSuccess) { on = false; return; }
             c->pool.push_back(e);
         }
         rec.cls = cls; rec.a = c->pool[c->pool_used++]; rec.b = c->pool[c->pool_used++];
-        (void)hipEventRecord(rec.a, s);
+    }
+    ProfScope(camal_ctx* ctx, hipStream_t st, int cls) : c(ctx), s(st), on(ctx && ctx->prof) {
+        if (!on) return;
+        take(cls);
+        if (on) (void)hipEventRecord(rec.a, s);
+    }
+    ProfScope(camal_ctx* ctx, hipStream_t st, int cls, OneKernel) : c(ctx), s(st), on(ctx && ctx->prof), one(true) {
+        if (on) take(cls);
+    }
+    template <typename... P, typename... A, size_t... I>
+    void launch_ev(void (*kern)(P...), dim3 grid, dim3 block, size_t lds, std::index_sequence<I...>, A&&... args) {
+        std::tuple<P...> params{static_cast<P>(args)...};  // the kernel's own parameter types
+        void* ptrs[] = {(void*)&std::get<I>(params)...};
+        (void)hipExtLaunchKernel((const void*)kern, grid, block, ptrs, lds, s, rec.a, rec.b, 0);
+    }
+    // the scope's one launch (kOneKernel form); errors surface through hipGetLastError like hipLaunchKernelGGL's
+    template <typename... P, typename... A>
+    void launch(void (*kern)(P...), dim3 grid, dim3 block, size_t lds, A&&... args) {
+        static_assert(sizeof...(P) == sizeof...(A), "kernel argument count");
+        if (on && one && !launched) {
+            launched = true;
+            launch_ev(kern, grid, block, lds, std::index_sequence_for<P...>{}, std::forward<A>(args)...);
+        } else {
+            hipLaunchKernelGGL(kern, grid, block, lds, s, static_cast<P>(args)...);
+        }
     }
     ~ProfScope() {
         if (!on) return;
+        if (one) {
+            if (launched) c->recs.push_back(rec);
+            else c->pool_used -= 2;  // nothing was launched: the pair goes back
+            return;
+        }
         (void)hipEventRecord(rec.b, s);
         c->recs.push_back(rec);
     }
@@ -395,10 +432,10 @@ int launch_conv_w(camal_ctx* c, int num_cu, size_t lds_per_cu, int cam_row, hipS
     static const int per_cu_cap = getenv("CAMAL_CONV_PER_CU") ? std::max(1, atoi(getenv("CAMAL_CONV_PER_CU"))) : 4;
     const int per_cu = std::max(1, std::min(per_cu_cap, (int)(lds_per_cu / lds)));
     const int grid = (int)std::min<long long>(total, (long long)num_cu * per_cu);
-    ProfScope ps(c, s, HEAD ? 2 : 1);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(G::THREADS), lds, s, (const DT*)in, (const uint4*)wpack, bias,
-                       (const DT*)res, (DT*)out, wfc, cam, part, L_out, ks, cam_row, tpw, (int)total, L_in, in_off,
-                       (const DT*)zero_row, cmax);
+    ProfScope ps(c, s, HEAD ? 2 : 1, kOneKernel);
+    ps.launch(kern, dim3(grid), dim3(G::THREADS), lds, (const DT*)in, (const uint4*)wpack, bias,
+              (const DT*)res, (DT*)out, wfc, cam, part, L_out, ks, cam_row, tpw, (int)total, L_in, in_off,
+              (const DT*)zero_row, cmax);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -476,8 +513,8 @@ int launch_block_w(camal_ctx* c, hipStream_t s, const Layer& l1, const Layer& l2
     a.total_tiles = (int)total;
     const int per_cu = std::max(1, (int)(c->lds_per_cu / lds));
     const int grid = (int)std::min<long long>(total, (long long)c->num_cu * per_cu);
-    ProfScope ps(c, s, HEAD ? 2 : 1);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(G::THREADS), lds, s, a);
+    ProfScope ps(c, s, HEAD ? 2 : 1, kOneKernel);
+    ps.launch(kern, dim3(grid), dim3(G::THREADS), lds, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -515,8 +552,8 @@ int launch_block1_w(camal_ctx* c, hipStream_t s, const Member& m, const float* x
     a.total_tiles = (int)total;
     const int per_cu = std::max(1, (int)(c->lds_per_cu / G::LDS_BYTES));
     const int grid = (int)std::min<long long>(total, (long long)c->num_cu * per_cu);
-    ProfScope ps(c, s, 1);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(G::THREADS), G::LDS_BYTES, s, a, m.stem_w, m.stem_b, m.res1_w, m.res1_b);
+    ProfScope ps(c, s, 1, kOneKernel);
+    ps.launch(kern, dim3(grid), dim3(G::THREADS), (size_t)G::LDS_BYTES, a, m.stem_w, m.stem_b, m.res1_w, m.res1_b);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -652,13 +689,13 @@ bool state_aligned(const PostArgs& a) { return a.state8_out ? ((uintptr_t)a.stat
 
 // post_stream_kernel for E members (1..8) and a 5-step moving average (the reference's default, core.py:257)
 template <bool F64>
-bool launch_post_stream(hipStream_t s, const PostArgs& a, int blocks) {
+bool launch_post_stream(ProfScope& ps, const PostArgs& a, int blocks) {
     const int segs = (a.L + POST_SEG - 1) / POST_SEG;
     const long long total = (long long)segs * a.B;
     if (total > 0x7fffffffLL) return false;
     const int grid = (int)std::min<long long>((total + 3) / 4, blocks);
     switch (a.E) {
-#define CAMAL_PS_CASE(NE) case NE: hipLaunchKernelGGL((post_stream_kernel<NE, F64, 5>), dim3(grid), dim3(256), 0, s, a, segs, (int)total); return true;
+#define CAMAL_PS_CASE(NE) case NE: ps.launch(post_stream_kernel<NE, F64, 5>, dim3(grid), dim3(256), (size_t)0, a, segs, (int)total); return true;
         CAMAL_PS_CASE(1) CAMAL_PS_CASE(2) CAMAL_PS_CASE(3) CAMAL_PS_CASE(4)
         CAMAL_PS_CASE(5) CAMAL_PS_CASE(6) CAMAL_PS_CASE(7) CAMAL_PS_CASE(8)
 #undef CAMAL_PS_CASE
@@ -668,19 +705,20 @@ bool launch_post_stream(hipStream_t s, const PostArgs& a, int blocks) {
 
 // own_max: no header_kernel ran; the kernel derives the votes and scans the rows for their maxima
 int launch_post(camal_ctx* c, hipStream_t s, const PostArgs& a0, bool own_max) {
-    ProfScope ps(c, s, 3);
     // the common case goes to the streaming kernel (wave-per-segment, no LDS): same arithmetic, bit-identical
     static const int stream_mode = getenv("CAMAL_POST_STREAM") ? atoi(getenv("CAMAL_POST_STREAM")) : 1;
     static const int stream_blocks = getenv("CAMAL_POST_STREAM_BLOCKS") ? atoi(getenv("CAMAL_POST_STREAM_BLOCKS")) : 0;
     if (stream_mode && !own_max && a0.hdr && !a0.x64 && !a0.avg_out && a0.w_ma == 5 && a0.L % 4 == 0 && a0.E <= 8 &&
         aligned16(a0.cam) && a0.cam_estride % 4 == 0 && aligned16(a0.x) && state_aligned(a0) && aligned16(a0.power_out)) {
         const int blocks = stream_blocks > 0 ? stream_blocks : (c ? c->num_cu : 256) * 16;  // measured flat from 12 to 64 per CU
-        const bool ok = a0.pred_f64 ? launch_post_stream<true>(s, a0, blocks) : launch_post_stream<false>(s, a0, blocks);
+        ProfScope ps1(c, s, 3, kOneKernel);
+        const bool ok = a0.pred_f64 ? launch_post_stream<true>(ps1, a0, blocks) : launch_post_stream<false>(ps1, a0, blocks);
         if (ok) {
             HIP_TRY(hipGetLastError());
             return 0;
         }
     }
+    ProfScope ps(c, s, 3);
     const int tiles = (a0.L + POST_TILE - 1) / POST_TILE;
     constexpr int kMaxY = 32768;  // grid.y limit is 65535
     // 16-byte accesses when every row of every array starts on a 16-byte boundary
