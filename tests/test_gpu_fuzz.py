@@ -1,0 +1,26 @@
+"""Randomised parity sweep (tools/fuzz_parity.py) as a GPU test: 40 drawn cases — member sets (first kernel sizes 1..41,
+mid_channels 32 / 64 / 128, the classifiers/resnet.py variant), window lengths on and next to the kernels' tile
+boundaries, chunking, precision, moving-average width, gate, float64 and signed data — against the CPU oracle with
+the tolerances of tests/test_gpu_parity.py.  The committed profiles/r03_fuzz_parity.json is the same sweep over 300
+cases."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+def test_random_cases_against_the_oracle():
+    import fuzz_parity as fz
+    rng = np.random.default_rng(2026)
+    failing = []
+    for i in range(40):
+        c = fz.draw(rng)
+        bad = fz.check(c, fz.run_case(c))
+        if bad:
+            failing.append((i, c, bad))
+    assert not failing, failing
