@@ -63,6 +63,7 @@ SIGNATURES = {
     "camal_trainer_destroy": (_i, [_vp]),
     "camal_trainer_set_grad_scale": (_i, [_vp, C.c_float]),
     "camal_train_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, C.c_float, _vp, _vp, _vp, _vp, _vp]),
+    "camal_trainer_peek": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, C.POINTER(_i), _vp]),
     "camal_train_bwd_dlogits": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "camal_ce_eval": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "camal_adamw_step": (_i, [_vp, _vp, _vp, _vp, _sz, _i, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),

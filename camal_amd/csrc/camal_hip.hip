@@ -466,7 +466,16 @@ int launch_conv_ex(camal_ctx* c, int num_cu, size_t lds_per_cu, int cam_row, hip
     }
     if constexpr (sizeof(DT) == 4) {
         using G8 = GeomW<DT, CIN, COUT, 8>;
-        if (2 * (size_t)G8::buf_bytes(ks) + (HEAD ? G8::HEAD_BYTES : 0) <= lds_per_cu || HEAD || TileNT<DT, CIN, COUT>::NT == 1)
+        const bool fits8 = 2 * (size_t)G8::buf_bytes(ks) + (HEAD ? G8::HEAD_BYTES : 0) <= lds_per_cu;
+        // one column tile per wave already and the eight-wave tile does not fit (256 -> 128 channels, the data gradient of
+        // mid_channels = 128's block 2, first kernel sizes from 19): ONE four-wave workgroup per CU on half the columns
+        if constexpr (COUT / 32 <= 4 && !HEAD && TileNT<DT, CIN, COUT>::NT == 1) {
+            using G4 = GeomW<DT, CIN, COUT, 4>;
+            if (!fits8 && 2 * (size_t)G4::buf_bytes(ks) <= lds_per_cu)
+                return launch_conv_w<DT, CIN, COUT, 4, RELU, HAS_RES, HEAD>(c, num_cu, lds_per_cu, cam_row, s, wpack, bias, ks, in,
+                                                                            res, out, wfc, cam, part, BC, L_out, L_in, in_off, zero_row, cmax);
+        }
+        if (fits8 || HEAD || TileNT<DT, CIN, COUT>::NT == 1)
             return launch_conv_w<DT, CIN, COUT, 8, RELU, HAS_RES, HEAD>(c, num_cu, lds_per_cu, cam_row, s, wpack, bias, ks, in,
                                                                         res, out, wfc, cam, part, BC, L_out, L_in, in_off, zero_row, cmax);
         // kernel sizes past 33 on 128 channels: one column tile per wave (64-step tiles)

@@ -540,6 +540,36 @@ int camal_train_bwd_dlogits(camal_trainer* t, const float* params, const float* 
     return train_bwd_impl<C1>(t, params, x, y, dlogits, B, L, grads, nullptr, loss_out, ncorrect_out, s);
 }
 
+int camal_trainer_peek(camal_trainer* t, int what, int index, int B, int L, float* out_dev, size_t out_floats,
+                       int* channels_out, void* stream) {
+    if (!t || !channels_out) return fail(CAMAL_ERR_ARG, "null argument");
+    if (B < 1 || B > t->maxB || L < 1 || L > t->maxL) return fail(CAMAL_ERR_ARG, "B or L exceeds what the trainer was created for");
+    const TLayer* zl[11];
+    for (int i = 0; i < 9; ++i) zl[t->lay.conv[i].zi] = &t->lay.conv[i];
+    zl[t->lay.res[0].zi] = &t->lay.res[0];
+    zl[t->lay.res[1].zi] = &t->lay.res[1];
+    const float* src = nullptr;
+    size_t n = 0;
+    if (what == CAMAL_PEEK_ACT) {
+        if (index < 0 || index >= 9) return fail(CAMAL_ERR_ARG, "activation index must be 0..8");
+        *channels_out = t->lay.conv[index].cout;
+        src = t->act[index];
+        n = (size_t)B * L * *channels_out;
+    } else {
+        if (index < 0 || index >= 11) return fail(CAMAL_ERR_ARG, "slot index must be 0..10");
+        *channels_out = zl[index]->cout;
+        if (what == CAMAL_PEEK_Z) { src = t->z[index]; n = (size_t)B * L * *channels_out; }
+        else if (what == CAMAL_PEEK_MEAN) { src = t->mean + index * 256; n = *channels_out; }
+        else if (what == CAMAL_PEEK_INVSTD) { src = t->invstd + index * 256; n = *channels_out; }
+        else return fail(CAMAL_ERR_ARG, "what must be one of CAMAL_PEEK_*");
+    }
+    if (!out_dev) return 0;
+    if (out_floats < n) return fail(CAMAL_ERR_ARG, "output buffer too small");
+    HIP_TRY(hipSetDevice(t->device));
+    HIP_TRY(hipMemcpyAsync(out_dev, src, n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
 int camal_ce_eval(const float* logits, const int* labels, int B, float* loss_out, int* pred_out, void* stream) {
     if (!logits || !labels || !loss_out || !pred_out) return fail(CAMAL_ERR_ARG, "null argument");
     if (B < 1) return fail(CAMAL_ERR_ARG, "B must be >= 1");

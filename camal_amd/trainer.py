@@ -299,6 +299,25 @@ class TrainEngine:
                                                     self.BN_MOMENTUM, None, _lib.ptr(logits), None, None, self._stream()))
         return logits
 
+    PEEK = {"z": 0, "act": 1, "mean": 2, "invstd": 3}
+
+    def peek(self, what, index, B, L):
+        """A copy of what the last forward pass (B windows of L steps) left in the workspace (camal_trainer_peek):
+        ``what`` = "z" (pre-BatchNorm conv output of slot ``index`` -> [B, L, C]), "act" (ConvBlock / block output ->
+        [B, L, C]), "mean" / "invstd" (batch statistics -> [C]).  For layer-level parity tests (the reference's
+        counterpart is a forward hook on the module)."""
+        import ctypes as C
+        ch = C.c_int()
+        code = self.PEEK[what]
+        _lib.check(self.lib.camal_trainer_peek(self._h, code, int(index), int(B), int(L), None, 0, C.byref(ch), None))
+        stat = what in ("mean", "invstd")
+        n = ch.value if stat else int(B) * int(L) * ch.value
+        with torch.cuda.device(self.device):
+            out = torch.empty(n, dtype=torch.float32, device=self.device)
+            _lib.check(self.lib.camal_trainer_peek(self._h, code, int(index), int(B), int(L), _lib.ptr(out), n, C.byref(ch),
+                                                   self._stream()))
+        return out if stat else out.view(int(B), int(L), ch.value)
+
     # ---- the training set resident in HBM ------------------------------------------------------------
     RESIDENT_FRACTION = 0.25  # of the GPU's free memory a training set may take to stay resident
 

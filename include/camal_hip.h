@@ -289,6 +289,21 @@ int camal_train_bwd_dlogits(camal_trainer* t, const float* params_dev, const flo
                             const float* dlogits_dev, int B, int L, float* grads_dev, float* loss_dev, int* ncorrect_dev,
                             void* stream);
 
+/* The activations the last camal_train_fwd_bwd left in the trainer's workspace, for layer-level parity tests (what a
+ * forward hook on a module shows in the reference, class_activation_map.py:8-12 being the one it registers itself):
+ *   what = CAMAL_PEEK_Z       pre-BatchNorm conv output of slot `index` [B][L][C]; slots in model.parameters() order:
+ *                             block 1: conv 0, 1, 2, skip conv; block 2: conv 0, 1, 2, skip conv; block 3: conv 0, 1, 2
+ *          CAMAL_PEEK_ACT     ConvBlock / block outputs 0..8 [B][L][C] (channels-last)
+ *          CAMAL_PEEK_MEAN / CAMAL_PEEK_INVSTD   batch statistics of slot `index` [C]
+ * Copies B*L*C (Z, ACT) or C (MEAN, INVSTD) floats into out_dev on `stream` (out_floats = its capacity; out_dev
+ * NULL: only *channels_out = C is returned).  B, L: the shape of that last call.                                    */
+#define CAMAL_PEEK_Z 0
+#define CAMAL_PEEK_ACT 1
+#define CAMAL_PEEK_MEAN 2
+#define CAMAL_PEEK_INVSTD 3
+int camal_trainer_peek(camal_trainer* t, int what, int index, int B, int L, float* out_dev, size_t out_floats,
+                       int* channels_out, void* stream);
+
 /* Evaluation loss of BasedClassifTrainer.evaluate / __evaluate (torch_trainer.py:188-193,316-321) from eval-mode
  * logits (camal_forward_cam): per-window cross-entropy (float32, -log_softmax[label]) and predicted label (argmax,
  * the first maximum like torch.max).  logits_dev [B][2] float32, labels_dev [B] int32, loss_out [B] float32,

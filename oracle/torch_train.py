@@ -18,10 +18,15 @@ from camal_amd import weights
 
 
 class FunctionalResNet:
-    def __init__(self, sd, dtype=torch.float32):
+    def __init__(self, sd, dtype=torch.float32, relu_masks=None):
         """dtype=torch.float64: the same arithmetic without float32 rounding (what both float32 implementations
-        approximate), for tests whose tolerance is close to the rounding noise of small batches."""
+        approximate), for tests whose tolerance is close to the rounding noise of small batches.
+        relu_masks: {(block, conv): bool array [B, C, L]} — the ReLU of that ConvBlock becomes a multiplication by the
+        given 0/1 mask (the mask another implementation's forward pass took): the step then differentiates exactly
+        the piecewise-linear function that implementation evaluated, whichever side of zero float32 rounding put its
+        borderline pre-activations on."""
         self.dtype = dtype
+        self.relu_masks = relu_masks or {}
         sd = weights.to_numpy_state_dict(sd)
         self.k = weights.kernel_size_of(sd)
         self.arch = weights.arch_of(sd)  # "resnet": classifiers/resnet.py's ResNet, zero "same" padding (:62)
@@ -51,7 +56,11 @@ class FunctionalResNet:
                 k = w.shape[-1]
                 hp = F.pad(h, (k // 2, k // 2)) if self.arch == weights.ARCH_RESNET else F.pad(h, (k // 2, k // 2), mode="replicate")
                 h = F.conv1d(hp, w, p[pre + ".layers.0.bias"])
-                h = F.relu(self._bn(h, pre + ".layers.1", training))
+                o = self._bn(h, pre + ".layers.1", training)
+                if (b, i) in self.relu_masks:
+                    h = o * torch.as_tensor(np.asarray(self.relu_masks[(b, i)]), dtype=self.dtype)
+                else:
+                    h = F.relu(o)
             if f"layers.{b}.residual.0.weight" in p:
                 r = F.conv1d(x, p[f"layers.{b}.residual.0.weight"], p[f"layers.{b}.residual.0.bias"])
                 h = h + self._bn(r, f"layers.{b}.residual.1", training)
@@ -66,13 +75,18 @@ class FunctionalResNet:
         return out
 
 
-def loss_and_grads(sd, x, y, criterion=None):
+def loss_and_grads(sd, x, y, criterion=None, dtype=torch.float32, relu_masks=None):
     """One train-mode forward/backward -> (loss, ncorrect, {key: grad}, updated state dict).  criterion: the trainer's
-    `criterion` argument (torch_trainer.py:20,290); None = nn.CrossEntropyLoss()."""
-    m = FunctionalResNet(sd)
-    logits = m.forward(torch.as_tensor(np.asarray(x, np.float32)))
+    `criterion` argument (torch_trainer.py:20,290); None = nn.CrossEntropyLoss().  dtype=torch.float64: the same step
+    without float32 rounding (see FunctionalResNet), to tell an implementation's error from the reference's own noise."""
+    m = FunctionalResNet(sd, dtype=dtype, relu_masks=relu_masks)
+    logits = m.forward(torch.as_tensor(np.asarray(x, np.float32)).to(dtype))
     labels = torch.as_tensor(np.asarray(y)).float().long()
-    loss = F.cross_entropy(logits.float(), labels) if criterion is None else criterion(logits.float(), labels)
+    if dtype == torch.float32:
+        logits_l = logits.float()
+    else:
+        logits_l = logits
+    loss = F.cross_entropy(logits_l, labels) if criterion is None else criterion(logits_l, labels)
     loss.backward()
     m.nbt += 1
     grads = {k: m.p[k].grad.numpy().copy() for k in m.keys}
