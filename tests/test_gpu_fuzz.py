@@ -24,3 +24,17 @@ def test_random_cases_against_the_oracle():
         if bad:
             failing.append((i, c, bad))
     assert not failing, failing
+
+
+def test_random_postprocessing_cases_exact():
+    """tools/fuzz_post.py: camal_postprocess on drawn CAM rows / logits (1..12 members, any length, moving-average widths
+    1..15, gates, float64 data, NaN / inf / all-negative rows) against the oracle: states and averaged CAM bit for bit."""
+    import fuzz_post as fp
+    rng = np.random.default_rng(2028)
+    failing = []
+    for i in range(200):
+        c = fp.draw(rng)
+        bad = fp.check(c, fp.run_case(c))
+        if bad:
+            failing.append((i, c, bad))
+    assert not failing, failing
