@@ -38,3 +38,19 @@ def test_random_postprocessing_cases_exact():
         if bad:
             failing.append((i, c, bad))
     assert not failing, failing
+
+
+def test_random_host_side_cases():
+    """tools/fuzz_host.py: the window builder and the metric sums against their oracles (bit for bit / 1e-12), and the host
+    pipeline (localize_host, localize_host_sharded: chunking, result dtypes, out= arrays, gates) against one call of
+    localize on all windows (bit for bit)."""
+    import fuzz_host as fh
+    rng = np.random.default_rng(2029)
+    failing = []
+    for i in range(120):
+        draw, run = list(fh.KINDS.values())[i % 3]
+        c = draw(rng)
+        bad = run(c)
+        if bad:
+            failing.append((i, c, bad))
+    assert not failing, failing
