@@ -458,7 +458,13 @@ class CamAL(object):
         list_resnet_predictors, list_cam_predictors, sds = [], [], []
         for resnet_name in self.camal_logs["camal_predictors_id"]:
             log = self.camal_logs["ensemble_training_logs"][resnet_name]
-            resnet_inst = CamALResNet(kernel_size=log["kernel_size"])  # defaults, like core.py:386-390
+            # The reference rebuilds DEFAULT models here (core.py:386-390), so an ensemble trained with
+            # CamAL(mid_channels=32 / 128) fails in its own load_state_dict; the width is read from the checkpoint instead
+            # (64 gives the reference's model unchanged).
+            sd_best = log["best_model_state_dict"]
+            mid = int(np.asarray(sd_best["layers.0.layers.0.layers.0.weight"].cpu() if torch.is_tensor(
+                sd_best["layers.0.layers.0.layers.0.weight"]) else sd_best["layers.0.layers.0.layers.0.weight"]).shape[0])
+            resnet_inst = CamALResNet(kernel_size=log["kernel_size"], mid_channels=mid)
             resnet_inst.to(self.device)
             resnet_inst.load_state_dict(log["best_model_state_dict"])
             resnet_inst.eval()

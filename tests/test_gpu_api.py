@@ -367,3 +367,31 @@ def test_localize_sequence_is_capturable_in_a_hip_graph():
         torch.cuda.synchronize()
         assert all(torch.equal(got[k], out[k]) for k in got)
     ens.close()
+
+
+@pytest.mark.parametrize("mid", [32, 128])
+def test_camal_train_predict_test_on_other_widths(mid):
+    """CamAL(mid_channels=...) end to end with the reference's default kernel list (core.py:47-56): train, the eval() that
+    follows it, predict, test.  The reference's eval() rebuilds default-width models (core.py:386-390) and fails in
+    load_state_dict for any other width; here the width is read from the checkpoint.  mid_channels = 128 with k = 25 also
+    needs the four-wave data-gradient tile (256 -> 128 channels)."""
+    from camal_amd import CamAL, synth
+    L = 96
+    x, y = synth.ideal_windows(64, L, seed=3)
+    xv, yv = synth.ideal_windows(12, L, seed=4)
+    xt, yt = synth.ideal_windows(12, L, seed=5)
+    m = CamAL(n_predictors=3, device="cuda:0", mid_channels=mid)
+    m.train((x, y), (xv, yv), (xt, yt), list_kernel_sizes=[5, 7, 9, 15, 25], n_try_by_kernel=1, epochs=2, batch_size=32)
+    assert all(p.mid_channels == mid for p in m.list_resnet_predictors)
+    states, prob = m.predict(xt, return_prob=True)
+    assert states.shape == xt.shape and prob.shape == (len(xt), 1) and np.isfinite(prob).all()
+    m.precision = "bf16"
+    m.eval()
+    _, prob16 = m.predict(xt, return_prob=True)
+    assert np.abs(prob16 - prob).max() < 5e-2
+    data4 = np.zeros((len(xt), 2, 2, L))
+    data4[:, 0, 0, :] = xt
+    data4[:, 1, 0, :] = xt * 0.5
+    data4[:, 1, 1, :] = xt > 1.0
+    loc, clf = m.test(data4)
+    assert "F1_SCORE" in loc and "ACCURACY" in clf
