@@ -532,6 +532,8 @@ class BasedClassifTrainer(object):
 
         self.train_time = round((time.time() - tmp_time), 3)
         self.engine.store_to_model(self.model)
+        if self.plotloss:
+            self.plot_history()
         self.log["training_time"] = self.train_time
         self.log["loss_train_history"] = self.loss_train_history
         self.log["loss_valid_history"] = self.loss_valid_history
@@ -557,6 +559,37 @@ class BasedClassifTrainer(object):
 
     def save(self):
         torch.save(self.log, self.path_checkpoint + ".pt")
+
+    def compress(self):
+        """The saved log as an .xz file in place of the .pt one (torch_trainer.py:216-233)."""
+        import lzma
+        with open(self.path_checkpoint + ".pt", "rb") as f:
+            data = f.read()
+        with open(self.path_checkpoint + ".xz", "wb") as f:
+            f.write(lzma.compress(data))
+        os.remove(self.path_checkpoint + ".pt")
+
+    def plot_history(self):
+        """Loss curves (torch_trainer.py:235-250): to ``path_fig`` if given, else shown."""
+        import matplotlib.pyplot as plt
+        plt.figure()
+        plt.plot(range(self.passed_epochs), self.loss_train_history[:self.passed_epochs], label="Train loss")
+        if self.valid_loader is not None:
+            plt.plot(range(self.passed_epochs), self.loss_valid_history[:self.passed_epochs], label="Valid loss")
+        plt.ylabel("Loss")
+        plt.xlabel("Epochs")
+        plt.legend()
+        if self.path_fig:
+            plt.savefig(self.path_fig)
+        else:
+            plt.show()
+
+    def reduce_lr(self, new_lr):
+        """The learning rate of the following steps (torch_trainer.py:252-258; the reference's body reaches for
+        ``self.model.optimizer``, which does not exist — the intent is what is done here)."""
+        self.lr = float(new_lr)
+        if self.scheduler is not None:
+            self.scheduler.lr = float(new_lr)
 
     def restore_best_weights(self):
         try:

@@ -456,3 +456,47 @@ def test_control_path_collectives_use_a_gpu_tensor_under_rccl(monkeypatch):
     fake.calls.clear()
     list(TSLoader(np.zeros((10, 4), np.float32), np.arange(10) % 2, batch_size=4, shuffle=True))
     assert fake.calls == []
+
+
+def test_trainer_host_helpers_save_compress_plot_reduce_lr(tmp_path):
+    """save / compress / plot_history / reduce_lr of BasedClassifTrainer (torch_trainer.py:209-258), host state only."""
+    import lzma
+    import os
+
+    import matplotlib
+    matplotlib.use("Agg")
+    import torch
+    from camal_amd.trainer import BasedClassifTrainer
+
+    class FakeModel:
+        def state_dict(self):
+            return {"w": 1}
+
+    class FakeEngine:
+        def _dp(self):
+            return False
+
+        def store_to_model(self, model):
+            pass
+
+        def optimizer_state_dict(self, lr, wd):
+            return {"lr": lr}
+
+    tr = BasedClassifTrainer.__new__(BasedClassifTrainer)
+    fig, ckpt = str(tmp_path / "loss.png"), str(tmp_path / "model")
+    tr._init_host(FakeModel(), [], [0], 1e-3, 0, None, 2, "cpu", False, 0, None, plotloss=True, path_fig=fig,
+                  save_checkpoint=True, path_checkpoint=ckpt)
+    tr.engine = FakeEngine()
+    losses = iter([(0.9, 0.5), (0.7, 0.6), (0.6, 0.7)])
+    tr._BasedClassifTrainer__train = lambda: next(losses)
+    tr._BasedClassifTrainer__evaluate = lambda: (0.8, 0.55)
+    tr.train(3)
+    assert os.path.getsize(fig) > 0                       # plotloss=True draws the curves at the end of train()
+    log = torch.load(ckpt + ".pt", weights_only=False)   # a file this test wrote
+    assert log["loss_train_history"] == [0.9, 0.7, 0.6] and "best_model_state_dict" in log
+    tr.compress()
+    assert not os.path.exists(ckpt + ".pt")
+    with open(ckpt + ".xz", "rb") as f:
+        assert len(lzma.decompress(f.read())) > 0
+    tr.reduce_lr(1e-5)
+    assert tr.lr == 1e-5 and tr.scheduler.lr == 1e-5
