@@ -506,6 +506,15 @@ class CamAL(object):
             _lib.check(lib.camal_attention(_lib.ptr(s_d), _lib.ptr(x_d), B, L, int(w_ma), _lib.ptr(out), stream))
         return out.cpu().numpy()
 
+    def moving_average(self, x: np.array, w: int) -> np.array:
+        """One row's moving average with zero edges (core.py:439-449), on the host: kept for callers of the reference's
+        public helper; predict's fused kernel has its own."""
+        return np.convolve(x, np.ones(w), "same") / w
+
+    def sigmoid(self, z):
+        """The rectified sigmoid 2 s(z) - 1 (core.py:451-461), on the host."""
+        return 2 * (1.0 / (1.0 + np.exp(-z))) - 1
+
     def _predict_subsequence_class(self, model, data) -> np.array:
         """Batched argmax of one member's logits (core.py:463-482)."""
         model.to(self.device)
