@@ -230,7 +230,8 @@ int t_wgrad(camal_trainer* t, hipStream_t s, const TLayer& l, const float* dz, c
         const int ng = (l.ks + WG_TAPS - 1) / WG_TAPS, base = l.ks / ng, rem = l.ks % ng;
         const int nhi_taps = rem ? base + 1 : base, n_hi = rem ? rem : ng;
         constexpr int CIW = WgCIW<CI, CO>::V;
-        const dim3 g(CI / 32 / CIW, ng, nsplit), blk(CO * 2 * CIW);
+        const dim3 g = CAMAL_WGRAD_CI_FAST ? dim3(CI / 32 / CIW, ng, nsplit) : dim3(nsplit, ng, CI / 32 / CIW);
+        const dim3 blk(CO * 2 * CIW);
         switch (nhi_taps) {
 #define CAMAL_WG_CASE(NT) \
     case NT: hipLaunchKernelGGL((wgrad_kernel<CI, CO, NT>), g, blk, 0, s, dz, ain, t->wg_part, B, L, l.ks, wps, n_hi, t->zpad()); break;

@@ -462,6 +462,9 @@ __global__ __launch_bounds__(256) void fold_edges_kernel(const float* __restrict
 // Partial results go to part[split][j][co][ci]; wgrad_reduce_kernel sums the splits in a fixed order.
 #define WG_TAPS 8
 #define WG_TT 64
+#ifndef CAMAL_WGRAD_CI_FAST
+#define CAMAL_WGRAD_CI_FAST 0
+#endif
 
 // NTAP (taps of this workgroup's group) is a template parameter: with a run-time count every MFMA sat behind its
 // own branch, LDS read and lgkmcnt(0) (the kernel ran at 0.32 of the fp32 peak).
@@ -492,10 +495,15 @@ __device__ __forceinline__ void wgrad_body(float (*s_dz)[COUT], float (*s_a)[32]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int cot = wave % WPT, cis = wave / WPT;        // this wave's co tile and ci tile inside the workgroup
-    const int cig0 = blockIdx.x * CIW * 32;              // first input channel of the workgroup
+    // grid = (splits, tap groups, ci tiles) with the split fastest: workgroup ids are dealt to the 8 XCDs round robin, and
+    // the ci tiles / tap groups of ONE split (they all read the same dz rows, and neighbouring 128-byte pieces of the same
+    // input rows) sit splits x groups ids apart, a multiple of 8 for the usual split counts: the same XCD, one L2
+    // (CAMAL_WGRAD_CI_FAST=1: ci tile fastest, the four readers of a dz tile on four XCDs)
+    const int cit = CAMAL_WGRAD_CI_FAST ? blockIdx.x : blockIdx.z;
+    const int cig0 = cit * CIW * 32;                     // first input channel of the workgroup
     const int ci0 = cig0 + cis * 32;
     const int arow0 = cis * (TT + WG_TAPS);              // this wave's ci tile inside s_a
-    const int split = blockIdx.z, pad = ks >> 1;
+    const int split = CAMAL_WGRAD_CI_FAST ? blockIdx.z : blockIdx.x, pad = ks >> 1;
     // a split = a run of consecutive (window, TT-step tile) pairs: finer than whole windows, so that layers with few
     // (ci tile, tap group) pairs (64 channels: 2) still put three workgroups on every CU at a batch of 128
     const int tpw = (L + TT - 1) / TT;
@@ -569,8 +577,8 @@ __device__ __forceinline__ void wgrad_body(float (*s_dz)[COUT], float (*s_a)[32]
         }
     };
 #if defined(CAMAL_STAMPS) && CAMAL_STAMPS == 4
-#define WSTAMP(k) do { if (CIN == 128 && COUT == 128 && NTAP == 7 && tile == 2 && blockIdx.x == 0 && blockIdx.z < 256 && lane == 0) \
-    g_stamps[blockIdx.z][wave][k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define WSTAMP(k) do { if (CIN == 128 && COUT == 128 && NTAP == 7 && tile == 2 && cit == 0 && split < 256 && lane == 0) \
+    g_stamps[split][wave][k] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define WSTAMP(k) do {} while (0)
 #endif
