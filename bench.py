@@ -572,7 +572,12 @@ def main():
             r = fn(n, dict(WORKLOADS[n]), args.steps, min(args.warmup, 3), R, args, min_seconds=args.also_seconds)
         except Exception as e:  # noqa: BLE001 — one workload failing must not cost the others their figures
             if world > 1:
-                raise  # the other ranks are inside collectives: fail the job (the deadline prints what exists)
+                # the other ranks are inside collectives: the job fails, but rank 0 first prints the line it has (the
+                # headline is complete at this point; the watchdog is a daemon thread and would die with the exception)
+                line.setdefault("also", {})[n] = {"error": f"{type(e).__name__}: {e}"}
+                dog.cancel()
+                emit()
+                raise
             r = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:
             line.setdefault("also", {})[n] = r
