@@ -4,7 +4,8 @@ Public surface mirrors the reference (adrienpetralia/CamAL):
     from camal_amd import CamAL, CamALResNet, CAM
 Everything heavy is imported lazily so that ``import camal_amd`` works without a GPU.
 """
-__all__ = ["CamAL", "CamALResNet", "ResNet", "CAM", "Ensemble", "NILMmetrics", "Classifmetrics"]
+__all__ = ["CamAL", "CamALResNet", "ResNet", "CAM", "Ensemble", "NILMmetrics", "Classifmetrics", "BasedClassifTrainer", "TSLoader",
+           "TSDataset", "NILMscaler"]
 
 
 def __getattr__(name):
@@ -26,4 +27,10 @@ def __getattr__(name):
     if name in ("NILMmetrics", "Classifmetrics"):
         from . import metrics
         return getattr(metrics, name)
+    if name in ("BasedClassifTrainer", "TSLoader", "TSDataset"):
+        from . import trainer
+        return getattr(trainer, name)
+    if name == "NILMscaler":
+        from .windows import NILMscaler
+        return NILMscaler
     raise AttributeError(name)

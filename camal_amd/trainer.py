@@ -80,6 +80,64 @@ class TSLoader:
             yield self.samples[idx], self.labels[idx]
 
 
+class TSDataset(torch.utils.data.Dataset):
+    """The reference's map-style dataset (torch_dataset.py:197-250): ``samples`` [n, C, L] (a 2-D X gets the channel
+    axis), ``labels`` [n] or None, optional per-channel StandardScaler (sklearn, as there).  What callers of the
+    reference wrap in a ``DataLoader`` and hand to ``BasedClassifTrainer``: the trainer here takes that loader as it is
+    (``as_tsloader``)."""
+
+    def __init__(self, X, labels=None, scaler=False, scale_dim=None):
+        X = X.values if hasattr(X, "values") else X          # a pandas DataFrame
+        labels = labels.values if hasattr(labels, "values") else labels
+        if scaler:
+            from sklearn.preprocessing import StandardScaler
+            if len(X.shape) == 3:
+                self.scaler_list, self.samples = [], X
+                for i in (range(X.shape[1]) if scale_dim is None else scale_dim):
+                    self.scaler_list.append(StandardScaler())
+                    self.samples[:, i, :] = self.scaler_list[-1].fit_transform(X[:, i, :].T).T.astype(np.float32)
+            else:
+                self.scaler_list = [StandardScaler()]
+                self.samples = self.scaler_list[0].fit_transform(X.T).T.astype(np.float32)
+        else:
+            self.samples = X
+        if len(self.samples.shape) == 2:
+            self.samples = np.expand_dims(self.samples, axis=1)
+        if labels is not None:
+            self.labels = labels.ravel()
+            assert len(self.samples) == len(self.labels), (
+                f"Number of X sample {len(self.samples)} doesn't match number of y sample {len(self.labels)}.")
+        else:
+            self.labels = labels
+
+    def __len__(self):
+        return len(self.samples)
+
+    def __getitem__(self, idx):
+        if self.labels is None:
+            return self.samples[idx]
+        return self.samples[idx], self.labels[idx]
+
+
+def as_tsloader(loader):
+    """A ``TSLoader`` for what the caller passed: a TSLoader itself, or a ``torch.utils.data.DataLoader`` over a dataset
+    with ``samples`` / ``labels`` arrays (the reference's ``DataLoader(TSDataset(X, y), batch_size, shuffle)``,
+    core.py:92-119) — same batch size, shuffling iff its sampler is a RandomSampler, its generator.  The trainer needs the
+    arrays themselves (the training set stays resident in HBM, evaluation runs as one batched forward), not a stream of
+    collated batches.  None stays None; anything else is returned unchanged (an iterable of (ts, labels) batches still
+    trains, one host-to-device copy per batch)."""
+    if loader is None or isinstance(loader, TSLoader):
+        return loader
+    ds = getattr(loader, "dataset", None)
+    if isinstance(loader, torch.utils.data.DataLoader) and hasattr(ds, "samples") and getattr(ds, "labels", None) is not None:
+        if loader.batch_size is None or getattr(loader, "drop_last", False):
+            raise ValueError("BasedClassifTrainer takes DataLoaders with a batch_size and drop_last=False")
+        shuffle = isinstance(loader.sampler, torch.utils.data.RandomSampler)
+        return TSLoader(np.asarray(ds.samples), np.asarray(ds.labels), batch_size=loader.batch_size, shuffle=shuffle,
+                        generator=loader.generator)
+    return loader
+
+
 class EarlyStopper:
     """torch_trainer.py:1098-1113."""
 
@@ -431,6 +489,7 @@ class BasedClassifTrainer(object):
         if valid_criterion is None:
             valid_criterion = criterion
         self.valid_criterion = None if valid_criterion is None or _is_default_ce(valid_criterion) else valid_criterion
+        train_loader, valid_loader = as_tsloader(train_loader), as_tsloader(valid_loader)
         self._init_host(model, train_loader, valid_loader, learning_rate, weight_decay, patience_es, patience_rlr, device,
                         all_gpu, n_warmup_epochs, f_metrics, verbose, plotloss, save_fig, path_fig, save_checkpoint,
                         path_checkpoint)
@@ -546,7 +605,7 @@ class BasedClassifTrainer(object):
     # ---------------------------------------------------------- evaluate (torch_trainer.py:173-207)
     def evaluate(self, test_loader, mask="test_metrics", return_output=False):
         tmp_time = time.time()
-        losses, y, y_hat = self._eval_loader(test_loader)
+        losses, y, y_hat = self._eval_loader(as_tsloader(test_loader))
         metrics = self.f_metrics(y, y_hat)
         self.eval_time = round((time.time() - tmp_time), 3)
         self.log[mask + "_time"] = self.eval_time

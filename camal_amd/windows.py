@@ -110,6 +110,34 @@ class NILMscaler:
         return r[0] if flag else r
 
 
+    def _channel_inverse(self, data, stats):
+        """data [n, C, L] (or [C, L]): channel c -> x * mul_c + add_c for the (mul, add) pairs of ``stats``; NumPy or torch."""
+        try:
+            import torch
+            is_t = torch.is_tensor(data)
+        except ImportError:
+            is_t = False
+        r = data.clone() if is_t else data.copy()
+        if len(r.shape) == 2:
+            r = r.unsqueeze(0) if is_t else np.expand_dims(r, axis=0)
+        for c, (mul, add) in enumerate(stats):
+            r[:, c, :] = r[:, c, :] * mul + add
+        return r
+
+    def inverse_transform_appliance(self, data):
+        """torch_dataset.py:158-176: appliance power channels [n, M, L] back to watts."""
+        assert self.appliance_scaling_type is not None, "Original data : no scaling apply on appliance channels!"
+        mm = self._minmax("appliance")
+        return self._channel_inverse(data, [((a2 - a1) if mm else a2, a1)
+                                            for a1, a2 in zip(self.appliance_stat1[:self.n_appliance], self.appliance_stat2)])
+
+    def inverse_transform_agg_power(self, data):
+        """torch_dataset.py:178-193: channel 0 of [n, C, L] back to watts with the aggregate's statistics (the reference
+        picks the MinMax form from the APPLIANCE scaling type there, :189: kept)."""
+        s1, s2 = self.power_stat1, self.power_stat2
+        return self._channel_inverse(data, [((s2 - s1) if self._minmax("appliance") else s2, s1)])
+
+
 def n_windows(T, window_size, window_stride):
     """data_processing.py:377-380."""
     if T < window_size:

@@ -500,3 +500,49 @@ def test_trainer_host_helpers_save_compress_plot_reduce_lr(tmp_path):
         assert len(lzma.decompress(f.read())) > 0
     tr.reduce_lr(1e-5)
     assert tr.lr == 1e-5 and tr.scheduler.lr == 1e-5
+
+
+def test_dataloader_over_tsdataset_becomes_the_same_tsloader():
+    """BasedClassifTrainer takes the reference's DataLoader(TSDataset(X, y), batch_size, shuffle) (core.py:92-119): the
+    loader built from it walks the same batches in the same order under torch.manual_seed as the DataLoader itself."""
+    import numpy as np
+    import torch
+    from camal_amd.trainer import TSDataset, TSLoader, as_tsloader
+    rng = np.random.default_rng(0)
+    X, y = rng.normal(size=(23, 40)).astype(np.float32), rng.integers(0, 2, 23)
+    ds = TSDataset(X, y)
+    assert ds.samples.shape == (23, 1, 40) and len(ds) == 23 and ds[3][1] == y[3]
+    for shuffle in (False, True):
+        dl = torch.utils.data.DataLoader(ds, batch_size=5, shuffle=shuffle)
+        tl = as_tsloader(dl)
+        assert isinstance(tl, TSLoader) and tl.batch_size == 5 and tl.shuffle == shuffle and len(tl) == len(dl)
+        torch.manual_seed(11)
+        ref = [(ts.numpy(), lb.numpy()) for ts, lb in dl]
+        torch.manual_seed(11)
+        got = list(tl)
+        assert len(ref) == len(got)
+        for (a, b), (c, d) in zip(ref, got):
+            assert np.array_equal(a, c) and np.array_equal(b, d)
+    assert as_tsloader(None) is None and as_tsloader(tl) is tl
+    scaled = TSDataset(rng.normal(3.0, 2.0, size=(6, 50)), scaler=True)
+    assert np.allclose(scaled.samples.mean(axis=-1), 0, atol=1e-5) and scaled.labels is None
+
+
+def test_scaler_channel_inverses_match_inverse_transform():
+    """NILMscaler.inverse_transform_appliance / inverse_transform_agg_power (torch_dataset.py:158-193) against
+    inverse_transform on the same channels, NumPy and torch."""
+    import numpy as np
+    import torch
+    from camal_amd.windows import NILMscaler
+    rng = np.random.default_rng(1)
+    data = np.abs(rng.normal(200, 80, size=(9, 2, 2, 30)))
+    for kind in ("StandardScaling", "MaxScaling", 1000):
+        sc = NILMscaler(power_scaling_type=kind, appliance_scaling_type="SameAsPower")
+        scaled = sc.fit_transform(data.copy())
+        back = sc.inverse_transform(scaled)
+        assert np.allclose(back[:, :, 0, :], data[:, :, 0, :])
+        app = sc.inverse_transform_appliance(scaled[:, 1:, 0, :])
+        agg = sc.inverse_transform_agg_power(scaled[:, :1, 0, :])
+        assert np.allclose(app[:, 0], data[:, 1, 0, :]) and np.allclose(agg[:, 0], data[:, 0, 0, :])
+        app_t = sc.inverse_transform_appliance(torch.from_numpy(scaled[0, 1:, 0, :]))
+        assert torch.is_tensor(app_t) and app_t.shape == (1, 1, 30) and np.allclose(app_t.numpy()[0, 0], data[0, 1, 0, :])

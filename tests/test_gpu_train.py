@@ -406,3 +406,29 @@ def test_camal_train_over_devices_from_one_process():
     for n in a["ensemble_training_logs"]:
         la, lb = a["ensemble_training_logs"][n], b["ensemble_training_logs"][n]
         assert la["loss_train_history"] == lb["loss_train_history"] and la["loss_valid_history"] == lb["loss_valid_history"]
+
+
+def test_trainer_takes_the_references_dataloaders():
+    """DataLoader(TSDataset(X, y), batch_size, shuffle=True) as CamAL.train builds them in the reference (core.py:92-119)
+    handed to BasedClassifTrainer: the same run, number for number, as with TSLoader (same shuffles under manual_seed)."""
+    import torch
+    from camal_amd import synth
+    from camal_amd.resnet import CamALResNet
+    from camal_amd.trainer import BasedClassifTrainer, TSDataset, TSLoader
+    x, y = synth.ideal_windows(50, 64, seed=21)
+    xv, yv = synth.ideal_windows(10, 64, seed=22)
+    runs = []
+    for kind in ("tsloader", "dataloader"):
+        torch.manual_seed(5)
+        m = CamALResNet(kernel_size=5)
+        if kind == "tsloader":
+            tl, vl, te = TSLoader(x, y, batch_size=16, shuffle=True), TSLoader(xv, yv, batch_size=1), TSLoader(xv, yv, batch_size=1)
+        else:
+            tl = torch.utils.data.DataLoader(TSDataset(x, y), batch_size=16, shuffle=True)
+            vl = torch.utils.data.DataLoader(TSDataset(xv, yv), batch_size=1, shuffle=False)
+            te = torch.utils.data.DataLoader(TSDataset(xv, yv), batch_size=1, shuffle=False)
+        tr = BasedClassifTrainer(m, train_loader=tl, valid_loader=vl, learning_rate=1e-3, weight_decay=0, device="cuda:0")
+        tr.train(3)
+        loss, metrics = tr.evaluate(te)
+        runs.append((tr.loss_train_history, tr.loss_valid_history, loss, metrics))
+    assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2] and runs[0][3] == runs[1][3]
