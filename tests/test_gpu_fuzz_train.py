@@ -34,3 +34,17 @@ def test_wide_model_large_first_kernels_train():
     for k in (19, 25, 49):
         c = {"arch": "camal", "mid": 128, "k": k, "L": 150, "B": 5, "max_batch": 5, "seed": 11 + k}
         assert not fz.check(c, fz.run_case(c)), k
+
+
+def test_random_trainer_runs_stay_with_the_cpu_trajectory():
+    """tools/fuzz_trainer.py: epochs of AdamW steps through BasedClassifTrainer (ragged last batches down to one window,
+    resident and per-batch-copy paths, weight decay) against torch autograd + AdamW on the CPU; thresholds in the tool."""
+    import fuzz_trainer as ft
+    rng = np.random.default_rng(2030)
+    failing = []
+    for i in range(24):
+        c = ft.draw(rng)
+        bad = ft.check(c, ft.run_case(c))
+        if bad:
+            failing.append((i, c, bad))
+    assert not failing, failing
