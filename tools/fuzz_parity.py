@@ -55,11 +55,16 @@ def draw(rng):
     else:
         pool = [1, 3, 5, 7, 9, 11, 15, 21, 25, 31, 41]
         c["ks"] = [int(k) for k in rng.choice(pool, size=int(rng.integers(1, 4)), replace=False)]
+        if rng.random() < 0.08:  # large ensembles: past 8 members the tiled post-processing kernel takes over, 16 is the limit
+            c["ks"] = [int(k) for k in rng.choice(pool[:7], size=int(rng.integers(6, 17)))]
+            c["mid"] = 64
     if rng.random() < 0.6:
         c["L"] = int(max(1, rng.choice(EDGES) + rng.integers(-3, 4)))
     else:
         c["L"] = int(rng.integers(1, 2101))
     c["B"] = int(rng.integers(1, 7))
+    if len(c["ks"]) > 3:
+        c["L"], c["B"] = min(c["L"], 600), min(c["B"], 3)  # keeps the oracle's share of a large ensemble in seconds
     c["chunk"] = int(rng.integers(1, 5)) if rng.random() < 0.3 else 0
     c["w_ma"] = 4 if rng.random() < 0.15 else 5
     c["gated"] = bool(rng.random() < 0.2)
