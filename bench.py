@@ -104,7 +104,7 @@ class Ranks:
         if self.dist is None:
             return v
         import torch
-        t = torch.tensor([v], dtype=torch.float64, device=self.dev)
+        t = torch.tensor([v], dtype=torch.float64, device="cpu" if self.dist.get_backend() == "gloo" else self.dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -507,6 +507,12 @@ def main():
 
     import torch
     dist = None
+    # CAMAL_BENCH_REHEARSAL=1 (tests, a one-GPU box): every rank runs on cuda:0 and the process group is "gloo" (RCCL
+    # refuses two ranks on one device), so that the WHOLE N > 1 flow of this file — ranks other than 0, barriers, MAX,
+    # the data-parallel training step with its all-reduce — runs on real kernels before the first multi-GPU node sees it
+    rehearsal = os.environ.get("CAMAL_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     dev = f"cuda:{local_rank}"
     if not args.dry_run:
         torch.cuda.set_device(local_rank)
@@ -518,6 +524,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dry_run:
             dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))
+        elif rehearsal:
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
         else:
             dist.init_process_group("nccl", device_id=torch.device(dev), timeout=datetime.timedelta(seconds=300))
     if args.dry_run:

@@ -161,3 +161,23 @@ def test_bench_launcher_path_under_rccl_at_world_1():
     line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["process_group"] == "nccl"
     assert all(v == v and v < 5.0 for v in line["sanity"]["loss"])  # finite losses after the all-reduced steps
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """The WHOLE N > 1 flow of bench.py on real kernels before a multi-GPU node sees it: `--gpus 2` starts its own two
+    ranks; CAMAL_BENCH_REHEARSAL=1 puts both on cuda:0 under "gloo" (RCCL refuses two ranks on one device).  Ranks other
+    than 0, the barriers and MAX around every timed region, the step counts agreed between ranks, the data-parallel
+    training step with its per-member all-reduce, every `also` workload, rank 0's single JSON line."""
+    root, env = _env(CAMAL_BENCH_REHEARSAL="1")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                        "--also", "all", "--also-seconds", "0.2", "--no-cpu-baseline", "--no-extras"], env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines  # rank 0 alone prints
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["process_group"] == "gloo" and line["scaling"] == "weak"
+    assert set(line["also"]) == {"ensemble_bf16", "ensemble_fp32", "long_bf16", "train_fp32"}
+    assert all("error" not in r and r["value"] > 0 for r in line["also"].values()), line["also"]
+    assert "x2" in line["also"]["train_fp32"]["config"]["parallelism"]
+    assert all(v == v and v < 5.0 for v in line["also"]["train_fp32"]["sanity"]["loss"])
