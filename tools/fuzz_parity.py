@@ -68,6 +68,7 @@ def draw(rng):
     c["chunk"] = int(rng.integers(1, 5)) if rng.random() < 0.3 else 0
     c["w_ma"] = 4 if rng.random() < 0.15 else 5
     c["gated"] = bool(rng.random() < 0.2)
+    c["use_y"] = bool(rng.random() < 0.15)  # the caller's per-window labels (predict's y, core.py:297-300)
     c["f64"] = bool(rng.random() < 0.2)
     c["signed"] = bool(rng.random() < 0.15)
     c["seed"] = int(rng.integers(0, 1 << 30))
@@ -100,14 +101,16 @@ def run_case(c):
     try:
         logits, cam = ens.forward_cam(x)
         logits, cam = logits.cpu().numpy(), cam.cpu().numpy()
-        res = ens.localize(x, x64=data if c["f64"] else None, w_ma=c["w_ma"], gate_mode=int(c["gated"]), pred_f64=c["f64"],
+        y = np.random.default_rng(seed).integers(0, 2, B).astype(np.int8) if c.get("use_y") else None
+        res = ens.localize(x, x64=data if c["f64"] else None, y=y, w_ma=c["w_ma"], gate_mode=int(c["gated"]), pred_f64=c["f64"],
                            want_avg_cam=True, p_on=2000.0, scale_mul=1000.0)
         torch.cuda.synchronize()
         prob, state = res["prob"].cpu().numpy(), res["state"].cpu().numpy()
         avg, power = res["avg_cam"].cpu().numpy(), res["power"].cpu().numpy()
     finally:
         ens.close()
-    ostates, oprob, oavg, outs = oracle.camal_predict(sds, data, w_ma=c["w_ma"], gated=c["gated"], return_intermediate=True)
+    ostates, oprob, oavg, outs = oracle.camal_predict(sds, data, y=y, w_ma=c["w_ma"], gated=c["gated"] and y is None,
+                                                      return_intermediate=True)
     oprob = np.asarray(oprob).reshape(-1)
     cam_err = prob_err = 0.0
     for e, (cams, _labels, probs) in enumerate(outs):
