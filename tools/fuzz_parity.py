@@ -73,6 +73,9 @@ def draw(rng):
     c["signed"] = bool(rng.random() < 0.15)
     c["seed"] = int(rng.integers(0, 1 << 30))
     c["fused"] = bool(rng.random() < 0.8)
+    # a window shorter than the moving average: np.convolve(..., 'same') returns w values there and the reference's own
+    # predict fails on the shapes (out of contract); the sweep keeps L >= w_ma
+    c["L"] = max(c["L"], c["w_ma"])
     return c
 
 
