@@ -202,6 +202,9 @@ def test_hand_counted_weight_ring_is_untouched_by_the_compiler(tmp_path):
     text = asm.read_text()
     assert text.count("ASMSTART") > 100 and "v_mfma_f32_16x16x32_bf16" in text
     assert check_ring.check(str(asm)) == []
+    # ... and it did look at the kernels: LLVM prints a function's label as "name:   ; @name", which an earlier version
+    # of the checker did not recognise as a label (it then walked no kernel of real output and reported nothing)
+    assert check_ring.check.kernels_seen > 100
 
 
 def test_ring_checker_sees_hazards_and_follows_out_of_line_blocks(tmp_path):
@@ -216,9 +219,9 @@ def test_ring_checker_sees_hazards_and_follows_out_of_line_blocks(tmp_path):
     mfma = "\tv_mfma_f32_16x16x32_bf16 v[40:43], v[10:13], v[20:23], v[40:43]\n"
     tail = "\ts_endpgm\n.LBB0_9:\n\tds_read_b128 v[10:13], v2\n\ts_branch .LBB0_2\n"
 
-    def run(body):
+    def run(body, label="_ZN5camal4testEv:                     ; @_ZN5camal4testEv\n"):
         f = tmp_path / "k.s"
-        f.write_text("_ZN5camal4testEv:\n" + body)
+        f.write_text(label + body)  # the label as LLVM prints it, comment included
         return check_ring.check(str(f))
 
     assert run(load + mfma + "\tv_mov_b32_e32 v10, 0\n\ts_endpgm\n") == []

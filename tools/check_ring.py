@@ -86,14 +86,18 @@ def check(path):
     kernels, cur = [], None
     for n, line in enumerate(open(path), 1):
         t = line.strip()
-        if t.startswith(".amdhsa_kernel") or (t.endswith(":") and t.startswith("_Z") and "camal" in t):
-            if t.endswith(":"):
-                cur = (t[:-1], [])
+        # a function's label as LLVM prints it: "_ZN5camal...E:   ; @_ZN5camal...E" (the comment hid the colon from an
+        # earlier version of this test, which then checked no kernel of real compiler output at all)
+        head = t.split(";")[0].strip()
+        if t.startswith(".amdhsa_kernel") or (head.endswith(":") and head.startswith("_Z") and "camal" in head):
+            if head.endswith(":"):
+                cur = (head[:-1], [])
                 kernels.append(cur)
             continue
         if cur is not None:
             cur[1].append((n, t))
     findings = []
+    check.kernels_seen = len(kernels)
     for name, lines in kernels:
         # The scan follows the text.  Blocks the compiler moved out of line (cold paths at the end of a kernel) and
         # loop headers are entered with the loads in flight at EVERY branch that reaches them, forward or backward:
