@@ -2,7 +2,7 @@
 # Build a variant of the library for an A/B run ONLY if the ring checker passes on its device assembly:
 #   tools/safe_build.sh build/lib_variant.so [-DKNOB=1 ...]
 # (a variant whose in-flight weight-ring registers the compiler copies or spills faults the GPU: check on the CPU first)
-set -e
+set -e -o pipefail
 R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$1; shift
 ASM=$(mktemp /tmp/camal_XXXX.s)
