@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """BASELINE configs[2] at its stated scale on ONE GPU, host to host: N (default 10 M) synthetic REFIT-shaped meter-day
 windows (L = 1440, float32) in host memory -> Ensemble.localize_host (bf16 ensemble of five members) -> int8 states,
-float64 probabilities and float32 power in host memory.   tools/run_configs2_full.py [N] [out.json]
-Host memory: 4 + 1 + 4 bytes per timestamp = 130 GB at 10 M windows."""
+float64 probabilities and float32 power in host memory.   tools/run_configs2_full.py [N] [out.json] [L]
+Host memory: 4 + 1 + 4 bytes per timestamp = 130 GB at 10 M windows.  L = 10080: configs[4]'s week windows the same way."""
 import json
 import os
 import sys
@@ -20,9 +20,9 @@ from camal_amd.engine import Ensemble  # noqa: E402
 
 N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 outp = sys.argv[2] if len(sys.argv) > 2 else None
-L, ks = 1440, [5, 7, 9, 15, 25]
+L, ks = (int(sys.argv[3]) if len(sys.argv) > 3 else 1440), [5, 7, 9, 15, 25]
 t0 = time.time()
-base = synth.refit_windows(8192, L, seed=5)
+base = synth.refit_windows(8192 if L <= 2000 else 1024, L, seed=5)
 sds = calibrated_state_dicts(ks, seed=0, sample_x=base[:64], device="cuda:0", precision="fp32")
 ens = Ensemble(sds, device="cuda:0", precision="bf16")
 x = np.empty((N, L), np.float32)
@@ -34,7 +34,7 @@ for s in range(0, N, len(base)):  # distinct windows per block: rolled by the bl
 states = np.empty((N, L), np.int8)
 power = np.empty((N, L), np.float32)
 prob = np.empty((N,), np.float64)
-ens.localize_host(base[:4096], p_on=2000.0, scale_mul=1000.0)  # pins the pipeline's buffers
+ens.localize_host(base[:min(4096, len(base))], p_on=2000.0, scale_mul=1000.0)  # pins the pipeline's buffers
 print(f"inputs ready {time.time() - t0:.0f} s", flush=True)
 stop = threading.Event()
 
